@@ -1,0 +1,40 @@
+"""Shared helpers for the oracle and GPU parity tests."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from oracle import diffusion_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["A_numeric", "B_ragged", "M_mixed", "N_tf", "L_catonly"]
+
+
+def load_case(tag: str) -> dict:
+    with np.load(os.path.join(GOLDEN, f"case_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    d["K"] = d["K"].astype(np.int64)
+    d["Nn"] = int(d["Nn"])
+    d["T"] = int(d["T"])
+    d["sched"] = str(d["sched"])
+    d["d_layers"] = [int(v) for v in d["d_layers"]]
+    d["C"] = len(d["K"]) if int(d["K"][0]) != 0 else 0
+    d["S"] = int(d["K"].sum())
+    d["D"] = d["Nn"] + d["S"]
+    return d
+
+
+def case_params(c: dict) -> dict[str, torch.Tensor]:
+    return orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+
+
+def tt(a, dtype=None) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dtype) if dtype is not None else t
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double(), b.double()
+    return float(((a - b).abs() / b.abs().clamp_min(1e-6)).max()) if a.numel() else 0.0

@@ -1,0 +1,126 @@
+"""CPU: the oracle (oracle/diffusion_oracle.py) against vectors produced by the reference itself.
+
+Bit-exact where the reference's op sequence is restated op for op (tables, noising, categorical
+draws, per-record losses, fp64 reverse state); this is what pins the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_oracle as orc
+from tests.helpers import CASES, GOLDEN, case_params, load_case, tt
+
+SCHED_KEYS = [
+    "alphas", "log_alpha", "log_1_min_alpha", "log_cumprod_alpha", "log_1_min_cumprod_alpha", "alphas_cumprod",
+    "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+    "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2",
+    "posterior_log_variance_clipped", "posterior_variance_f64", "model_variance_f64", "model_log_variance_f64",
+]
+
+
+@pytest.mark.parametrize("tag,T,kind", [("cosine_1000", 1000, "cosine"), ("linear_100", 100, "linear")])
+def test_schedule_tables_bit_exact(tag, T, kind):
+    s = orc.make_schedule(T, kind)
+    with np.load(f"{GOLDEN}/sched_{tag}.npz") as z:
+        for k in SCHED_KEYS:
+            got = getattr(s, k).numpy()
+            assert got.dtype == z[k].dtype, k
+            assert np.array_equal(got, z[k]), k
+
+
+def test_schedule_known_answers():
+    # SURVEY.md section 8 a1 [probe] values (T=1000 cosine)
+    s = orc.make_schedule(1000, "cosine")
+    assert np.allclose(s.alphas_cumprod[[0, 500, 999]].numpy(), [0.999958694, 0.492285162, 2.42876697e-09], rtol=1e-7)
+    assert abs(float(s.log_1_min_alpha[0]) - (-10.0950298)) < 1e-6
+    assert abs(float(s.sqrt_recipm1_alphas_cumprod[999]) - 20291.1699) < 1e-2
+    assert float(s.posterior_variance_f64[1]) == 2.178949614569182e-05
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_mixed_loss_rows_bit_exact(tag):
+    c = load_case(tag)
+    s = orc.make_schedule(c["T"], c["sched"])
+    p = case_params(c)
+    x0, t, eps, u = tt(c["x0"]), tt(c["ml_t"]), tt(c["ml_eps"]), tt(c["ml_u"])
+    x_num_t, xt_idx = orc.q_sample_fused(s, c["K"], c["Nn"], x0, t, eps, u)
+    assert torch.equal(x_num_t, tt(c["ml_x_num_t"]))
+    assert torch.equal(xt_idx, tt(c["ml_xt_idx"]))
+    x_in = orc.model_input(x_num_t, xt_idx, c["K"])
+    assert torch.equal(x_in, tt(c["ml_model_in"]))
+    out = orc.mlp_forward(p, x_in, t)
+    assert torch.equal(out, tt(c["ml_model_out"]))
+    lm, lg = orc.loss_rows(s, c["K"], c["Nn"], out, x0, xt_idx, eps, t)
+    assert torch.equal(lm, tt(c["ml_lm_rows"]))
+    assert torch.equal(lg, tt(c["ml_lg_rows"]))
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_mixed_loss_means_match_reference_call(tag):
+    """The unmodified reference call (its own drawn t) vs the oracle with the captured draws."""
+    c = load_case(tag)
+    s = orc.make_schedule(c["T"], c["sched"])
+    lm, lg, m_mean, g_mean = orc.mixed_loss(s, c["K"], c["Nn"], case_params(c), tt(c["x0"]), tt(c["ml_ref_call_t"]),
+                                            tt(c["ml_eps"]), tt(c["ml_u"]))
+    ref = c["ml_ref_call_means"]
+    assert np.float32(m_mean) == ref[0] and np.float32(g_mean) == ref[1]
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "N_tf"])
+def test_tf_score_bit_exact(tag):
+    c = load_case(tag)
+    s = orc.make_schedule(c["T"], c["sched"])
+    p = case_params(c)
+    for k in range(4):
+        t, add = (int(v) for v in c[f"tf{k}_t"])
+        got = orc.tf_score(s, c["Nn"], p, tt(c["x0"]), tt(c["tf_noise"]), t, add)
+        assert torch.equal(got, tt(c[f"tf{k}_score"])), (k, t, add)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_reverse_steps_bit_exact(tag):
+    c = load_case(tag)
+    s = orc.make_schedule(c["T"], c["sched"])
+    Nn = c["Nn"]
+    for k in range(4):
+        t = int(c[f"rs{k}_t"])
+        mo = tt(c[f"rs{k}_model_out"])
+        if Nn:
+            z_new = orc.gaussian_p_step(s, mo[:, :Nn], tt(c[f"rs{k}_z"]), t, tt(c[f"rs{k}_n"]))
+            assert z_new.dtype == torch.float64
+            assert torch.equal(z_new, tt(c[f"rs{k}_z_new"])), (k, t)
+        if c["C"]:
+            idx = orc.multinomial_p_step(s, c["K"], mo[:, Nn:], tt(c[f"rs{k}_z_idx"]), t, tt(c[f"rs{k}_u"]))
+            assert torch.equal(idx, tt(c[f"rs{k}_z_idx_new"])), (k, t)
+            tv = torch.full((mo.shape[0],), t, dtype=torch.long)
+            logp = orc.q_posterior(s, orc.block_log_softmax(mo[:, Nn:], c["K"]), orc.log_onehot(tt(c[f"rs{k}_z_idx"]), c["K"]), tv, c["K"])
+            assert torch.equal(logp, tt(c[f"rs{k}_logp"]))
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly"])
+def test_full_chain_bit_exact(tag):
+    c = load_case(tag)
+    s = orc.make_schedule(int(c["ch_T"]), c["sched"])
+    first32 = bool(c["ch_first_noise_is_f32"])
+    noises = [tt(n) for n in c["ch_noise"]]
+    if first32 and len(noises):
+        noises[0] = noises[0].float()
+    us = [tt(v) for v in c["ch_u"]] if c["C"] else [None] * len(noises)
+    u0 = tt(c["ch_u0"]) if c["C"] else None
+    got = orc.sample_chain(s, c["K"], c["Nn"], case_params(c), tt(c["ch_z0"]), u0, noises, us)
+    want = tt(c["ch_sample"])
+    assert got.dtype == want.dtype == torch.float64
+    assert torch.equal(got, want)
+
+
+def test_scan_recurrence_equals_logcumsumexp():
+    """The scalar fp64 recurrence the HIP kernel implements == torch's block LSE, bit for bit."""
+    g = torch.Generator().manual_seed(7)
+    K = np.array([3, 7, 10, 2, 12])
+    off = orc.offsets_of(K)
+    un = torch.randn((64, int(off[-1])), generator=g) * 6 - 20
+    un[:, 5] = orc.LOG_TINY * 2
+    want = orc.block_lse_cumulative(un, K)[:, off[:-1]]
+    for r in range(un.shape[0]):
+        got = orc.scan_lse_scalar(un[r].numpy(), off)
+        assert np.array_equal(got, want[r].numpy()), r

@@ -1,0 +1,256 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (container only).
+
+Run:  python tools/make_golden.py
+The reference is imported through tools/ref_shim.py from /root/reference (read-only).  Every
+random draw the reference makes is captured by wrapping the torch RNG entry points it calls
+(randint / randn / randn_like / rand_like / multinomial), so each fixture holds the inputs, the
+injected noise and the reference's outputs.  Denoiser weights are NOT stored: they are rebuilt
+from a seed by oracle.diffusion_oracle.init_mlp_params (plain torch CPU RNG) and loaded into the
+reference module through load_state_dict, which keeps the fixtures small.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_shim  # noqa: E402
+
+gmd, du, model = ref_shim.load()
+from midst_toolkit.common.enumerations import IsTargetConditioned  # noqa: E402
+
+from oracle import diffusion_oracle as orc  # noqa: E402  (only for init_mlp_params / names)
+
+TF = ref_shim.load_tf()
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+CPU = torch.device("cpu")
+
+
+@contextlib.contextmanager
+def capture_rng(log: list):
+    names = ["randint", "randn", "randn_like", "rand_like", "multinomial"]
+    saved = {n: getattr(torch, n) for n in names}
+
+    def wrap(n):
+        def f(*a, **k):
+            out = saved[n](*a, **k)
+            log.append((n, out.clone()))
+            return out
+        return f
+
+    for n in names:
+        setattr(torch, n, wrap(n))
+    try:
+        yield
+    finally:
+        for n in names:
+            setattr(torch, n, saved[n])
+
+
+def build(K, Nn, d_layers, T, sched="cosine", seed=0):
+    K = np.asarray(K, dtype=np.int64)
+    D = Nn + int(K.sum())
+    params = orc.init_mlp_params(D, d_layers, seed=seed)
+    dp = model.DiffusionParameters(layers_dimensions=list(d_layers), dropout=0.0)
+    net = model.MLPDiffusion(D, 0, IsTargetConditioned.NONE, dp)
+    net.load_state_dict(params, strict=True)
+    net.eval()
+    st = gmd.SchedulerType.COSINE if sched == "cosine" else gmd.SchedulerType.LINEAR
+    diff = gmd.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, scheduler_type=st, device=CPU)
+    diff.eval()
+    return diff, params
+
+
+def synth_rows(B, K, Nn, g):
+    x = torch.randn((B, Nn), generator=g).clamp(-5.2, 5.2)
+    cols = [x]
+    for k in K:
+        if k > 0:
+            cols.append(torch.randint(0, int(k), (B, 1), generator=g).float())
+    return torch.cat(cols, dim=1)
+
+
+def has_cat(K):
+    return len(K) > 0 and int(K[0]) != 0
+
+
+def gen_schedule(tag, T, sched):
+    diff, _ = build([0], 2, [8], T, sched)
+    d = {k: v.numpy() for k, v in diff.state_dict().items() if not k.startswith("_denoise_fn")}
+    d["posterior_variance_f64"] = diff.posterior_variance.numpy()
+    d["posterior_log_variance_clipped"] = diff.posterior_log_variance_clipped.numpy()
+    d["posterior_mean_coef1"] = diff.posterior_mean_coef1.numpy()
+    d["posterior_mean_coef2"] = diff.posterior_mean_coef2.numpy()
+    mv = torch.cat([diff.posterior_variance[1].unsqueeze(0), (1.0 - diff.alphas)[1:]], dim=0)
+    d["model_variance_f64"] = mv.numpy()
+    d["model_log_variance_f64"] = torch.log(mv).numpy()
+    np.savez_compressed(os.path.join(OUT, f"sched_{tag}.npz"), T=T, sched=sched, **d)
+
+
+def gen_case(tag, K, Nn, d_layers, T, B, sched="cosine", P=4, T_chain=None):
+    K = np.asarray(K, dtype=np.int64)
+    C = len(K) if has_cat(K) else 0
+    S = int(K.sum())
+    g = torch.Generator().manual_seed(20250821)
+    diff, params = build(K, Nn, d_layers, T, sched)
+    x0 = synth_rows(B, K, Nn, g)
+    out: dict[str, np.ndarray] = dict(K=K, Nn=Nn, d_layers=np.asarray(d_layers), T=T, sched=sched, x0=x0.numpy())
+
+    # ---- mixed_loss, whole call with captured RNG, then replayed step by step for per-record rows
+    log: list = []
+    torch.manual_seed(1234)
+    with capture_rng(log), torch.no_grad():
+        m_mean, g_mean = diff.mixed_loss(x0, {"y": torch.zeros(B, dtype=torch.long)})
+    t = log[0][1].clone()
+    assert log[0][0] == "randint"
+    # force the edge timesteps into the batch, then recompute everything with injected noise
+    t[:4] = torch.tensor([0, 1, T - 1, 0])
+    eps = log[1][1] if Nn > 0 else torch.zeros((B, 0))
+    us = [e[1] for e in log[(2 if Nn > 0 else 1):]]
+    u = torch.cat(us, dim=1) if C else torch.zeros((B, 0))
+    assert u.shape[1] == (S if C else 0)
+    with torch.no_grad():
+        x_num_t = diff.gaussian_q_sample(x0[:, :Nn], t, noise=eps) if Nn > 0 else x0[:, :0]
+        if C:
+            log_x0 = du.index_to_log_onehot(x0[:, Nn:].long(), torch.from_numpy(K))
+            it = iter(us)
+            saved = torch.rand_like
+            torch.rand_like = lambda ref: next(it)  # inject the captured uniforms, block by block
+            try:
+                log_xt = diff.q_sample(log_features_start=log_x0, timestep=t)
+            finally:
+                torch.rand_like = saved
+            xt_idx = du.one_hot_encoding_to_categories(torch.exp(log_xt).round(), K)
+            x_in = torch.cat([x_num_t, log_xt], dim=1)
+        else:
+            xt_idx = torch.zeros((B, 0), dtype=torch.int64)
+            x_in = x_num_t
+        m_out = diff._denoise_fn(x_in, t)
+        lm_rows = torch.zeros((1,))
+        lg_rows = torch.zeros((1,))
+        if C:
+            p_t = torch.ones_like(t).float() / T
+            lm_rows = diff._multinomial_loss(m_out[:, Nn:], log_x0, log_xt, t, p_t) / len(K)
+        if Nn > 0:
+            lg_rows = diff._gaussian_loss(m_out[:, :Nn], x0[:, :Nn], x_num_t, t, eps)
+    out.update(ml_t=t.numpy(), ml_eps=eps.numpy(), ml_u=u.numpy(), ml_x_num_t=x_num_t.numpy(),
+               ml_xt_idx=xt_idx.numpy(), ml_model_in=x_in.numpy(), ml_model_out=m_out.numpy(),
+               ml_lm_rows=lm_rows.numpy(), ml_lg_rows=lg_rows.numpy(),
+               ml_ref_call_t=log[0][1].numpy(), ml_ref_call_means=np.array([m_mean.item(), g_mean.item()], dtype=np.float32))
+
+    # ---- Tartan-Federer scoring (numeric block only, TF:40-95); the real reference function
+    if Nn > 0:
+        noise = torch.randn((P, Nn), generator=g)
+        for k, (tt, add) in enumerate([(5, 0), (T // 2, 0), (T - 2, 1), (0, 0)]):
+            if C:
+                break  # TF feeds only the numeric block to the denoiser: valid only when S == 0
+            with torch.no_grad():
+                sc = TF.mixed_loss(diff, x0, {"y": torch.zeros(B * P, dtype=torch.long)}, noise.tolist(), P, add, tt)
+            out[f"tf{k}_t"] = np.array([tt, add])
+            out[f"tf{k}_score"] = sc.numpy()
+        out["tf_noise"] = noise.numpy()
+
+    # ---- single reverse steps with injected model_out / noise / uniforms (a16, a17)
+    for k, tt in enumerate([T - 1, T // 2, 1, 0]):
+        first = tt == T - 1
+        z = torch.randn((B, Nn), generator=g) * 1.3
+        z = z if first else z.double() + 1e-9 * torch.randn((B, Nn), generator=g, dtype=torch.float64)
+        mo = torch.randn((B, Nn + S), generator=g) * 2.0
+        n = torch.randn((B, Nn), generator=g, dtype=torch.float32 if first else torch.float64)
+        tvec = torch.full((B,), tt, dtype=torch.long)
+        saved_randn_like = torch.randn_like
+        torch.randn_like = lambda ref: n
+        try:
+            with torch.no_grad():
+                z_new = diff.gaussian_p_sample(mo[:, :Nn], z, tvec)["sample"] if Nn > 0 else z
+        finally:
+            torch.randn_like = saved_randn_like
+        out[f"rs{k}_t"] = np.array(tt)
+        out[f"rs{k}_z"] = z.numpy()
+        out[f"rs{k}_model_out"] = mo.numpy()
+        out[f"rs{k}_n"] = n.numpy()
+        out[f"rs{k}_z_new"] = z_new.numpy()
+        if C:
+            z_idx = torch.stack([torch.randint(0, int(kk), (B,), generator=g) for kk in K], dim=1)
+            u = torch.rand((B, S), generator=g)
+            off = np.concatenate([[0], np.cumsum(K)])
+            it = iter([u[:, off[c]:off[c + 1]] for c in range(C)])
+            saved = torch.rand_like
+            torch.rand_like = lambda ref: next(it)
+            try:
+                with torch.no_grad():
+                    log_z = du.index_to_log_onehot(z_idx, torch.from_numpy(K))
+                    logp = diff.p_pred(mo[:, Nn:], log_z, tvec)
+                    log_z_new = diff.log_sample_categorical(logp)
+            finally:
+                torch.rand_like = saved
+            out[f"rs{k}_z_idx"] = z_idx.numpy()
+            out[f"rs{k}_u"] = u.numpy()
+            out[f"rs{k}_logp"] = logp.numpy()
+            out[f"rs{k}_z_idx_new"] = du.one_hot_encoding_to_categories(torch.exp(log_z_new).round(), K).numpy()
+
+    # ---- a full reverse chain on a short schedule, every draw captured (a18)
+    if T_chain:
+        diff2, _ = build(K, Nn, d_layers, T_chain, sched)
+        Bc = min(B, 64)
+        log2: list = []
+        torch.manual_seed(4321)
+        with capture_rng(log2):
+            smp, outs = diff2.sample(Bc, torch.ones(1))
+        kinds = [e[0] for e in log2]
+        assert kinds[0] == "randn"
+        pos = 1
+        out["ch_z0"] = log2[0][1].numpy()
+        if C:
+            out["ch_u0"] = torch.cat([e[1] for e in log2[pos:pos + C]], dim=1).numpy()
+            pos += C
+        assert kinds[pos] == "multinomial"
+        pos += 1
+        ns, uss = [], []
+        for i in range(T_chain):
+            assert kinds[pos] == "randn_like", (i, kinds[pos])
+            ns.append(log2[pos][1].double().numpy())  # fp32 on the first step, fp64 after: stored as fp64
+            pos += 1
+            if C:
+                uss.append(torch.cat([e[1] for e in log2[pos:pos + C]], dim=1).numpy())
+                pos += C
+        assert pos == len(log2)
+        out["ch_T"] = np.array(T_chain)
+        out["ch_noise"] = np.stack(ns)
+        out["ch_first_noise_is_f32"] = np.array(log2[1 + (C if C else 0) + 1][1].dtype == torch.float32)
+        if C:
+            out["ch_u"] = np.stack(uss)
+        out["ch_sample"] = smp.numpy()
+        assert smp.dtype == torch.float64
+
+    np.savez_compressed(os.path.join(OUT, f"case_{tag}.npz"), **out)
+    print(f"case {tag}: B={B} D={Nn + S} means={m_mean.item():.6f},{g_mean.item():.6f}")
+
+
+def main():
+    gen_schedule("cosine_1000", 1000, "cosine")
+    gen_schedule("linear_100", 100, "linear")
+    # A: the shipped pipeline's shape (numeric only, num_classes=[0]); also the Tartan-Federer shape
+    gen_case("A_numeric", [0], 8, [64, 64], 100, 96, T_chain=12)
+    # B: ragged categorical blocks incl. a 2-level one
+    gen_case("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 1000, 96, T_chain=16)
+    # M: BASELINE config M (20 numeric + 10x10 levels), 4x512 denoiser
+    gen_case("M_mixed", [10] * 10, 20, [512] * 4, 1000, 64, T_chain=8)
+    # N: Tartan-Federer shape, 4x512
+    gen_case("N_tf", [0], 20, [512] * 4, 1000, 64, P=4)
+    # L: linear schedule, categorical only
+    gen_case("L_catonly", [4, 4, 5], 0, [64, 64], 100, 48, sched="linear", T_chain=40)
+
+
+if __name__ == "__main__":
+    main()
