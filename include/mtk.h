@@ -1,0 +1,155 @@
+/*
+ * mtk.h — C ABI of libmtk_hip.so: the MI355X (gfx950) implementation of midst-toolkit's
+ * diffusion hot path (GaussianMultinomialDiffusion core + MLPDiffusion denoiser).
+ *
+ * The reference has no FFI; its seam is two Python nn.Module classes.  Each entry point below
+ * names the reference method(s) it replaces.  Paths are relative to
+ * src/midst_toolkit/ in the reference checkout:
+ *   GMD   = models/clavaddpm/gaussian_multinomial_diffusion.py
+ *   DU    = models/clavaddpm/diffusion_utils.py
+ *   MODEL = models/clavaddpm/model.py
+ *   TF    = attacks/tartan_federer/tartan_federer_attack.py
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative mtk_status; mtk_last_error() gives the
+ *     thread-local message of the last failure;
+ *   - pointers are DEVICE pointers unless the name ends in _host;
+ *   - nothing synchronises; all work is enqueued on the hipStream_t passed in (a void* here so the
+ *     header needs no HIP include; pass torch's current stream handle);
+ *   - matrices are described by (pointer, row stride, column stride) in ELEMENTS, so both the
+ *     reference's row-major [B, D] tensors (rs = D, cs = 1) and the column-major [D][B] layout the
+ *     fused path prefers (rs = 1, cs = B) are accepted;
+ *   - a context is bound to one device and may be used from one host thread at a time.
+ */
+#ifndef MTK_H
+#define MTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtk_ctx mtk_ctx;
+typedef void* mtk_stream; /* hipStream_t */
+
+enum mtk_status {
+    MTK_OK = 0,
+    MTK_ERR_ARG = -1,         /* bad shape / null pointer / unsupported size  (Python: AssertionError) */
+    MTK_ERR_UNSUPPORTED = -2, /* unsupported enum / configuration             (Python: ValueError)     */
+    MTK_ERR_HIP = -3,         /* a HIP runtime call failed                    (Python: RuntimeError)   */
+    MTK_ERR_STATE = -4        /* call order violated (e.g. forward before set_weights)                  */
+};
+
+/* Row order of tables_host passed to mtk_ctx_create: MTK_NTAB rows of T doubles each.  Rows 0..9
+ * hold the reference's fp32 buffers (exactly representable in a double); row 10 is the fp64
+ * log-variance row of the reverse chain, which the reference never casts to fp32 (GMD:223, 387-394). */
+enum mtk_table {
+    MTK_TAB_SQRT_ACP = 0,       /* sqrt_alphas_cumprod            GMD:263 */
+    MTK_TAB_SQRT_1M_ACP = 1,    /* sqrt_one_minus_alphas_cumprod  GMD:264 */
+    MTK_TAB_LOG_ALPHA = 2,      /* log_alpha                      GMD:254 */
+    MTK_TAB_LOG_1M_ALPHA = 3,   /* log_1_min_alpha                GMD:257 */
+    MTK_TAB_LOG_ACP = 4,        /* log_cumprod_alpha              GMD:255 */
+    MTK_TAB_LOG_1M_ACP = 5,     /* log_1_min_cumprod_alpha        GMD:258 */
+    MTK_TAB_SQRT_RECIP_ACP = 6, /* sqrt_recip_alphas_cumprod      GMD:265 */
+    MTK_TAB_SQRT_RECIPM1_ACP = 7, /* sqrt_recipm1_alphas_cumprod  GMD:266 */
+    MTK_TAB_POST_COEF1 = 8,     /* posterior_mean_coef1           GMD:226 */
+    MTK_TAB_POST_COEF2 = 9,     /* posterior_mean_coef2           GMD:228-230 */
+    MTK_TAB_MODEL_LOGVAR64 = 10, /* log([posterior_variance[1], (1-alphas)[1:]]) in fp64, GMD:387-394 */
+    MTK_NTAB = 11
+};
+
+/* Denoiser arithmetic. */
+enum mtk_precision {
+    MTK_PREC_FP32 = 0, /* f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 FMA chains */
+    MTK_PREC_BF16 = 1  /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16), fused over layers */
+};
+
+const char* mtk_last_error(void);
+int mtk_version(void);
+
+/* Replaces GaussianMultinomialDiffusion.__init__ table set-up (GMD:156-239) on the device side.
+ * K_host[C] are the category counts (C = 0 or K_host[0] == 0 means "no categorical block",
+ * the shipped pipeline's num_classes=[0]); logK_host[C] = float32 log(K) as the caller's torch
+ * computes it (GMD:739); tables_host is MTK_NTAB x T doubles (see enum mtk_table). */
+int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K_host, const float* logK_host,
+                   const double* tables_host, mtk_ctx** out);
+void mtk_ctx_destroy(mtk_ctx* ctx);
+
+/* Replaces MLPDiffusion's parameter storage (MODEL:548-594).  W[i] / b[i] are device pointers to
+ * fp32 PyTorch-layout weights [out_i][in_i] / [out_i], in this order:
+ *   0 proj, 1 timestep_embedding.0, 2 timestep_embedding.2, 3.. mlp.blocks.*.linear, last mlp.head
+ * dims_host = {D, dim_t, h_1 .. h_n} (n = n_hidden).  The call packs the weights into MFMA operand
+ * order (fp32 and bf16 images) and rebuilds the [T, dim_t] time-embedding table
+ * emb[t] = Linear(SiLU(Linear(sinusoid(t)))) (MODEL:123-144, 608).  freqs_host[dim_t/2] are the
+ * sinusoid frequencies as the caller's torch computes them (MODEL:136).  Call again after every
+ * optimizer step that changes the weights. */
+int mtk_mlp_set_weights(mtk_ctx* ctx, int n_hidden, const int32_t* dims_host, const float* const* W_host_ptrs,
+                        const float* const* b_host_ptrs, const float* freqs_host, mtk_stream stream);
+
+/* Replaces MLPDiffusion.forward(x, timesteps) (MODEL:596-615) with is_target_conditioned = NONE.
+ * x: [B, D] via (x_rs, x_cs); t: per-row int64 timesteps, or NULL to use t_scalar for every row;
+ * out: [B, D] via (o_rs, o_cs). */
+int mtk_mlp_forward(mtk_ctx* ctx, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
+                    int t_scalar, float* out, int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream);
+
+/* Replaces the noising half of mixed_loss (GMD:1025-1040): gaussian_q_sample (GMD:302),
+ * index_to_log_onehot (DU:209), q_pred (GMD:742), log_sample_categorical (GMD:852), q_sample (GMD:873).
+ * x0: [B, Nn + C] row-major with leading dimension x0_ld (numeric columns, then category codes as
+ * floats).  eps: [B, Nn] row-major (ld = Nn) or NULL → Philox normal(seed, row, col);  u: [B, S]
+ * row-major (ld = S) or NULL → Philox uniform.  Outputs: x_in = denoiser input [B, D]
+ * (numeric x_t, then the log-one-hot of the sampled categories) via (xi_rs, xi_cs);
+ * xt_idx: [C][B] int32 sampled category codes (column-major).  row0 is the global index of row 0
+ * (Philox counters use row0 + i so that results do not depend on how rows are sharded). */
+int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                 const float* u, float* x_in, int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed,
+                 uint64_t row0, mtk_stream stream);
+
+/* Replaces the loss half of mixed_loss (GMD:1044-1066): _gaussian_loss MSE branch (GMD:505-532),
+ * predict_start (GMD:761), q_posterior (GMD:781) with sliced_logsumexp (DU:268) restated as the
+ * fp64 running log-cum-sum-exp + fp32 log-sub-exp it is on torch-CPU, multinomial_kl (GMD:709),
+ * log_categorical (DU:195), kl_prior (GMD:887), compute_lt (GMD:907), _multinomial_loss (GMD:984).
+ * Per-record outputs (the reference only returns their means): loss_multi[B] already divided by C,
+ * loss_gauss[B].  Either may be NULL when that side is absent.  eps NULL → regenerate the Philox
+ * draws of mtk_q_sample(seed, row0). */
+int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, int64_t mo_rs, int64_t mo_cs, const float* x0,
+                  int64_t x0_ld, const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi,
+                  float* loss_gauss, uint64_t seed, uint64_t row0, mtk_stream stream);
+
+/* Replaces tartan_federer_attack.mixed_loss (TF:40-95) for n_t timesteps at once:
+ * score[k][r][p] = mean_d (noise[p][d] - eps_hat(x_t(r, p, t_k + add_t), t_k)[d])^2.
+ * x: [B, >=Nn] row-major (ld x_ld), noise: [P, Nn] row-major, t_list_host: n_t ints,
+ * score: [n_t][B][P] fp32.  Requires S == 0 (TF feeds only the numeric block, TF:86-91). */
+int mtk_tf_score(mtk_ctx* ctx, int64_t B, int P, const float* x, int64_t x_ld, const float* noise, int n_t,
+                 const int32_t* t_list_host, int add_t, float* score, int precision, mtk_stream stream);
+
+/* Replaces one iteration of the reverse loop of sample() (GMD:1403-1417) after the denoiser call:
+ * gaussian_p_sample (GMD:663) = gaussian_p_mean_variance (GMD:358) + _predict_features_start_from_eps
+ * (GMD:545) + gaussian_q_posterior_mean_variance (GMD:323), and p_sample (GMD:837) = p_pred (GMD:810)
+ * + log_sample_categorical (GMD:852).
+ * z: [Nn][B] fp64 state, updated in place (first_step != 0: the state holds fp32-representable
+ * values and the mean is formed in fp32 arithmetic, as torch's promotion does at t = T-1);
+ * z_idx: [C][B] int32, updated in place.  noise: [B, Nn] row-major, fp32 if noise_is_f64 == 0 else
+ * fp64, or NULL → Philox;  u: [B, S] row-major or NULL → Philox.  x_in_next: the next denoiser
+ * input [B, D] (float(z'), log-one-hot(z_idx')) via (xi_rs, xi_cs), may be NULL. */
+int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
+                      int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64, const float* u,
+                      float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0,
+                      mtk_stream stream);
+
+/* Replaces the initial draw of sample() (GMD:1392-1399): z0 [B, Nn] row-major fp32 (or NULL → Philox)
+ * into the fp64 state z [Nn][B]; categories by Gumbel-argmax of uniform logits from u0 [B, S]
+ * (or NULL → Philox) into z_idx [C][B]; and the first denoiser input. */
+int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, double* z, int32_t* z_idx,
+                    float* x_in, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream);
+
+/* Replaces the decode at the end of sample() (GMD:1419-1423; one_hot_encoding_to_categories, DU:121):
+ * sample[B, Nn + C] fp64 row-major = (z, category codes). */
+int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, double* sample,
+                      mtk_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTK_H */

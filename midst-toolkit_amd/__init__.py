@@ -1,0 +1,21 @@
+"""midst_toolkit_amd — MI355X-native diffusion hot path of midst-toolkit (drop-in classes)."""
+from .diffusion import (  # noqa: F401
+    FoundNaNsError,
+    GaussianLossType,
+    GaussianMultinomialDiffusion,
+    GaussianParametrization,
+    Parametrization,
+)
+from .engine import Engine  # noqa: F401
+from .model import (  # noqa: F401
+    MLP,
+    DiffusionParameters,
+    IsTargetConditioned,
+    MLPDiffusion,
+    ModelParameters,
+    ModelType,
+    timestep_frequencies,
+)
+from .schedule import SchedulerType, betas_for_alpha_bar, get_named_beta_schedule  # noqa: F401
+from .scoring import mixed_loss as tartan_federer_mixed_loss  # noqa: F401
+from .scoring import score_records  # noqa: F401

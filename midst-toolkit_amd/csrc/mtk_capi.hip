@@ -1,0 +1,88 @@
+// mtk_capi.hip — context lifetime and error reporting of libmtk_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "mtk_common.h"
+
+static thread_local char g_err[512] = "";
+
+void mtk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mtk_last_error(void) { return g_err; }
+extern "C" int mtk_version(void) { return 100; }
+
+void mtk_free_mlp(mtk_ctx* c);  // mtk_mlp_f32.hip
+
+extern "C" int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K_host, const float* logK_host,
+                              const double* tables_host, mtk_ctx** out) {
+    if (!out) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_create: out is null");
+    *out = nullptr;
+    if (T < 1 || Nn < 0 || C < 0 || !tables_host) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_create: bad T/Nn/C or null tables");
+    if (C > MTK_C_MAX) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_ctx_create: C = %d exceeds %d", C, MTK_C_MAX);
+    if (C > 0 && (!K_host || !logK_host)) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_create: K_host/logK_host required when C > 0");
+    if (C > 0 && K_host[0] == 0) C = 0;  // the reference's "num_classes = [0]" spelling of "no categorical block"
+    int n_dev = 0;
+    MTK_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_create: device %d of %d", device, n_dev);
+    MTK_HIP(hipSetDevice(device));
+
+    mtk_ctx* c = new mtk_ctx();
+    c->device = device;
+    c->T = T;
+    c->Nn = Nn;
+    c->C = C;
+    c->off.assign(1, 0);
+    for (int k = 0; k < C; ++k) {
+        if (K_host[k] < 1) {
+            delete c;
+            MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_create: K[%d] = %d", k, K_host[k]);
+        }
+        c->K.push_back(K_host[k]);
+        c->logK.push_back(logK_host[k]);
+        c->off.push_back(c->off.back() + K_host[k]);
+    }
+    c->S = c->off.back();
+    c->D = Nn + c->S;
+    c->tables.assign(tables_host, tables_host + (size_t)MTK_NTAB * T);
+
+    std::vector<SchedRow> rows(T);
+    for (int t = 0; t < T; ++t) {
+        rows[t].sqrt_acp = (float)c->tab(MTK_TAB_SQRT_ACP, t);
+        rows[t].sqrt_1m_acp = (float)c->tab(MTK_TAB_SQRT_1M_ACP, t);
+        rows[t].log_alpha = (float)c->tab(MTK_TAB_LOG_ALPHA, t);
+        rows[t].log_1m_alpha = (float)c->tab(MTK_TAB_LOG_1M_ALPHA, t);
+        rows[t].log_acp = (float)c->tab(MTK_TAB_LOG_ACP, t);
+        rows[t].log_1m_acp = (float)c->tab(MTK_TAB_LOG_1M_ACP, t);
+        rows[t].sqrt_recip_acp = (float)c->tab(MTK_TAB_SQRT_RECIP_ACP, t);
+        rows[t].sqrt_recipm1_acp = (float)c->tab(MTK_TAB_SQRT_RECIPM1_ACP, t);
+    }
+    std::vector<float> lk(c->logK);
+    if (lk.empty()) lk.push_back(0.0f);
+    hipError_t e = hipMalloc(&c->d_rows, sizeof(SchedRow) * T);
+    if (e == hipSuccess) e = hipMalloc(&c->d_off, sizeof(int32_t) * c->off.size());
+    if (e == hipSuccess) e = hipMalloc(&c->d_logK, sizeof(float) * lk.size());
+    if (e == hipSuccess) e = hipMemcpy(c->d_rows, rows.data(), sizeof(SchedRow) * T, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_off, c->off.data(), sizeof(int32_t) * c->off.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_logK, lk.data(), sizeof(float) * lk.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        mtk_ctx_destroy(c);
+        MTK_FAIL(MTK_ERR_HIP, "mtk_ctx_create: device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MTK_OK;
+}
+
+extern "C" void mtk_ctx_destroy(mtk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    mtk_free_mlp(c);
+    if (c->d_rows) (void)hipFree(c->d_rows);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_logK) (void)hipFree(c->d_logK);
+    delete c;
+}

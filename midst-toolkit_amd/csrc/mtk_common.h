@@ -1,0 +1,129 @@
+// mtk_common.h — shared host/device definitions for libmtk_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "mtk.h"
+
+// ----------------------------------------------------------------------------- errors
+void mtk_set_error(const char* fmt, ...);
+#define MTK_FAIL(code, ...)         \
+    do {                            \
+        mtk_set_error(__VA_ARGS__); \
+        return (code);              \
+    } while (0)
+#define MTK_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) MTK_FAIL(MTK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ----------------------------------------------------------------------------- schedule rows
+// One 32-byte row per timestep: the eight fp32 tables the per-row-t kernels gather.
+struct SchedRow {
+    float sqrt_acp, sqrt_1m_acp, log_alpha, log_1m_alpha, log_acp, log_1m_acp, sqrt_recip_acp, sqrt_recipm1_acp;
+};
+static_assert(sizeof(SchedRow) == 32, "SchedRow must be 32 bytes");
+
+// Device-side view of a context's constant data (passed to kernels by value).
+struct DevTables {
+    const SchedRow* rows;  // [T]
+    const int32_t* off;    // [C+1] one-hot column offsets
+    const float* logK;     // [C]
+    int T, Nn, C, S;
+};
+
+constexpr int MTK_LDS_T_MAX = 2048;  // schedule rows are staged in LDS up to this T (64 KB)
+constexpr int MTK_C_MAX = 1024;      // categorical columns staged in LDS
+
+// ----------------------------------------------------------------------------- denoiser storage
+struct MlpLayer {
+    int in = 0, out = 0;          // logical sizes
+    int in_pad = 0, out_pad = 0;  // padded to the fp32 GEMM tile (K: 32, N: 128)
+    float* w32 = nullptr;         // [out_pad][in_pad] fp32, zero padded
+    float* b32 = nullptr;         // [out_pad]
+};
+
+struct mtk_ctx {
+    int device = 0;
+    int T = 0, Nn = 0, C = 0, S = 0, D = 0;
+    std::vector<int32_t> K, off;
+    std::vector<float> logK;
+    std::vector<double> tables;  // MTK_NTAB x T host copy
+    SchedRow* d_rows = nullptr;
+    int32_t* d_off = nullptr;
+    float* d_logK = nullptr;
+    // denoiser
+    bool have_weights = false;
+    int dim_t = 0, n_hidden = 0;
+    std::vector<int> hidden;
+    MlpLayer proj, temb0, temb2, head;
+    std::vector<MlpLayer> blocks;
+    float* d_emb = nullptr;    // [T][dim_t_pad] time-embedding table
+    int emb_ld = 0;
+    // fused bf16 image (mtk_mlp_bf16.hip)
+    void* d_wfrag = nullptr;   // packed MFMA A-fragments, consumption order
+    size_t wfrag_bytes = 0;
+    float* d_bias_all = nullptr;  // concatenated padded biases for the fused kernel
+    bool fused_ok = false;
+    int fused_h = 0;
+    // workspace for the layered fp32 path
+    float* ws[2] = {nullptr, nullptr};
+    size_t ws_elems = 0;
+    // workspace of the unfused Tartan-Federer path (x_t and eps_hat, row-major [rows][Nn])
+    float* tf_ws[2] = {nullptr, nullptr};
+    size_t tf_ws_elems = 0;
+
+    DevTables dev() const { return DevTables{d_rows, d_off, d_logK, T, Nn, C, S}; }
+    double tab(int which, int t) const { return tables[(size_t)which * T + t]; }
+};
+
+// ----------------------------------------------------------------------------- device helpers
+#define MTK_LOG_TINY (-0x1.144f6ap+6f) /* fp32 log(1e-30f) = -69.07755, DU:227 */
+#define MTK_TINY (0x1.4484cp-100f)     /* 1e-30f */
+
+#ifdef __HIPCC__
+// Philox-4x32-10 (Salmon et al., SC'11).  Counter = (row_lo, row_hi, group, stream), key = seed.
+__device__ __forceinline__ uint4 mtk_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint64_t seed) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+__device__ __forceinline__ float mtk_u01(uint32_t x) { return (float)(x >> 8) * 0x1p-24f; }  // [0, 1)
+// Box-Muller on two 32-bit words -> two standard normals.
+__device__ __forceinline__ void mtk_normal2(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * 0x1p-24f;  // (0, 1]
+    const float u2 = (float)(b >> 8) * 0x1p-24f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+enum { MTK_STREAM_EPS = 1, MTK_STREAM_U = 2, MTK_STREAM_Z0 = 3, MTK_STREAM_U0 = 4, MTK_STREAM_STEP = 16 };
+// element j of the normal stream for `row`
+__device__ __forceinline__ float mtk_philox_normal(uint64_t seed, uint64_t row, uint32_t stream, int j) {
+    const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(j >> 2), stream, seed);
+    float n0, n1;
+    if ((j & 2) == 0) mtk_normal2(r.x, r.y, n0, n1); else mtk_normal2(r.z, r.w, n0, n1);
+    return (j & 1) ? n1 : n0;
+}
+__device__ __forceinline__ float mtk_philox_uniform(uint64_t seed, uint64_t row, uint32_t stream, int j) {
+    const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(j >> 2), stream, seed);
+    const uint32_t w = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
+    return mtk_u01(w);
+}
+#endif

@@ -1,0 +1,449 @@
+// mtk_diffusion.hip — fused, HBM-bound diffusion kernels for gfx950 (wave64).
+//
+// One lane per record.  Column-major intermediates ([D][B], [C][B]) make every per-lane loop a
+// fully coalesced 256-byte wave access; the reference's row-major inputs are read through strides.
+// Schedule rows (32 B per timestep) and the per-column category offsets / log K are staged in LDS
+// once per workgroup; workgroups are persistent (grid-stride over 256-record chunks).
+//
+// Built with -ffp-contract=off: every fp32 expression below is evaluated with the same roundings
+// as the reference's eager tensor ops (no fused multiply-add), so categorical draws can match.
+#include <math.h>
+
+#include "mtk_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Staged {
+    const SchedRow* rows;
+    const int32_t* off;
+    const float* logK;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char mtk_smem[];
+
+// Copies the schedule rows (when LDS_ROWS) and the categorical descriptors into LDS.
+template <bool LDS_ROWS>
+__device__ __forceinline__ Staged stage_tables(const DevTables& d) {
+    Staged s;
+    unsigned char* p = mtk_smem;
+    if (LDS_ROWS) {
+        float4* dst = reinterpret_cast<float4*>(p);
+        const float4* src = reinterpret_cast<const float4*>(d.rows);
+        for (int i = threadIdx.x; i < d.T * 2; i += blockDim.x) dst[i] = src[i];
+        s.rows = reinterpret_cast<const SchedRow*>(p);
+        p += (size_t)d.T * sizeof(SchedRow);
+    } else {
+        s.rows = d.rows;
+    }
+    int32_t* so = reinterpret_cast<int32_t*>(p);
+    float* sk = reinterpret_cast<float*>(p + (((size_t)(d.C + 1) * 4 + 15) & ~(size_t)15));
+    for (int i = threadIdx.x; i <= d.C; i += blockDim.x) so[i] = d.off[i];
+    for (int i = threadIdx.x; i < d.C; i += blockDim.x) sk[i] = d.logK[i];
+    s.off = so;
+    s.logK = sk;
+    __syncthreads();
+    return s;
+}
+
+// DU:155  m + log(e^{a-m} + e^{b-m})
+__device__ __forceinline__ float lae(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m + logf(expf(a - m) + expf(b - m));
+}
+// DU:250  log(e^{a-m} - e^{b-m}) + m
+__device__ __forceinline__ float lse_sub(float a, float b) {
+    const float m = fmaxf(a, b);
+    return logf(expf(a - m) - expf(b - m)) + m;
+}
+// torch-CPU logcumsumexp step (fp64 running value): r <- log1p(exp(min - max)) + max
+__device__ __forceinline__ void scan_push(double& r, float x) {
+    const double xd = (double)x;
+    const double hi = fmax(xd, r), lo = fmin(xd, r);
+    if (lo != hi || isfinite(lo)) r = log1p(exp(lo - hi)) + hi; else r = xd;
+}
+// GMD:866  -log(-log(u + 1e-30) + 1e-30)
+__device__ __forceinline__ float gumbel(float u) { return -logf(-logf(u + MTK_TINY) + MTK_TINY); }
+
+// ------------------------------------------------------------------------------------------------
+// q_sample: a4 (GMD:302) + a5 (DU:209) + a6 (GMD:742) + a7 (GMD:852, 873)
+// ------------------------------------------------------------------------------------------------
+struct QSampleArgs {
+    DevTables d;
+    int64_t B;
+    const float* x0; int64_t x0_ld;
+    const int64_t* t;
+    const float* eps;
+    const float* u;
+    float* x_in; int64_t xi_rs, xi_cs;
+    int32_t* xt_idx;
+    uint64_t seed, row0;
+};
+
+template <bool LDS_ROWS>
+__global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
+    const Staged s = stage_tables<LDS_ROWS>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int t = (int)a.t[row];
+        const SchedRow sr = s.rows[t];
+        const float* xr = a.x0 + row * a.x0_ld;
+        float* xo = a.x_in + row * a.xi_rs;
+        for (int j = 0; j < Nn; ++j) {
+            const float e = a.eps ? a.eps[row * Nn + j] : mtk_philox_normal(a.seed, a.row0 + row, MTK_STREAM_EPS, j);
+            xo[j * a.xi_cs] = sr.sqrt_acp * xr[j] + sr.sqrt_1m_acp * e;
+        }
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const int c0 = (int)(long long)xr[Nn + k];
+            const float c = sr.log_1m_acp - s.logK[k];
+            const float hot = lae(0.0f + sr.log_acp, c);
+            const float cold = lae(MTK_LOG_TINY + sr.log_acp, c);
+            float best = -INFINITY;
+            int arg = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float uu = a.u ? a.u[row * S + o + i] : mtk_philox_uniform(a.seed, a.row0 + row, MTK_STREAM_U, o + i);
+                const float v = gumbel(uu) + (i == c0 ? hot : cold);
+                if (v > best || i == 0) { best = v; arg = i; }
+            }
+            a.xt_idx[(int64_t)k * a.B + row] = arg;
+            for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss_rows: a9 (GMD:505) + a10 (GMD:761) + a11 (GMD:781, DU:250-289) + a13 (GMD:709, 887, 907, 984)
+// ------------------------------------------------------------------------------------------------
+struct LossArgs {
+    DevTables d;
+    int64_t B;
+    const float* mo; int64_t mo_rs, mo_cs;
+    const float* x0; int64_t x0_ld;
+    const int32_t* xt_idx;
+    const float* eps;
+    const int64_t* t;
+    float* loss_multi;
+    float* loss_gauss;
+    uint64_t seed, row0;
+};
+
+template <bool LDS_ROWS>
+__global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
+    const Staged s = stage_tables<LDS_ROWS>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
+    const SchedRow srT = s.rows[T - 1];
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int t = (int)a.t[row];
+        const float* mo = a.mo + row * a.mo_rs;
+        if (a.loss_gauss && Nn > 0) {  // mean_d (eps - eps_hat)^2
+            float acc = 0.0f;
+            for (int j = 0; j < Nn; ++j) {
+                const float e = a.eps ? a.eps[row * Nn + j] : mtk_philox_normal(a.seed, a.row0 + row, MTK_STREAM_EPS, j);
+                const float df = e - mo[j * a.mo_cs];
+                acc += df * df;
+            }
+            a.loss_gauss[row] = acc / (float)Nn;
+        }
+        if (!a.loss_multi || C == 0) continue;
+
+        const SchedRow st = s.rows[t];
+        const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
+        const float* xr = a.x0 + row * a.x0_ld;
+        double run_t = -INFINITY, run_m = -INFINITY;  // fp64 running log-cum-sum-exp over the WHOLE row
+        float cum_t0 = -INFINITY, cum_m0 = -INFINITY;
+        float kl = 0.0f, nll = 0.0f, prior = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const float logK = s.logK[k];
+            const int c0 = (int)(long long)xr[Nn + k];
+            const int ct = a.xt_idx[(int64_t)k * a.B + row];
+            const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+            // q(x_t | x_{t-1}) evaluated at the sampled x_t (GMD:722)
+            const float cq = st.log_1m_alpha - logK;
+            const float q_hot = lae(0.0f + st.log_alpha, cq), q_cold = lae(MTK_LOG_TINY + st.log_alpha, cq);
+            // q(x_{t-1} | x_0) for the true x_0 (GMD:796-800)
+            const float ce = s1.log_1m_acp - logK;
+            const float e_hot = (t == 0) ? 0.0f : lae(0.0f + s1.log_acp, ce);
+            const float e_cold = (t == 0) ? MTK_LOG_TINY : lae(MTK_LOG_TINY + s1.log_acp, ce);
+            // log-softmax of the block's logits (GMD:778)
+            float mx = -INFINITY;
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            float sum = 0.0f;
+            for (int i = 0; i < Kk; ++i) sum += expf(mc[i * a.mo_cs] - mx);
+            const float lsum = logf(sum);
+            for (int i = 0; i < Kk; ++i) {
+                const float qo = (i == ct) ? q_hot : q_cold;
+                const float un_t = ((i == c0) ? e_hot : e_cold) + qo;
+                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae(lsm + s1.log_acp, ce);
+                scan_push(run_t, un_t);
+                scan_push(run_m, ev + qo);
+            }
+            const float cum_t1 = (float)run_t, cum_m1 = (float)run_m;
+            const float lse_t = lse_sub(cum_t1, cum_t0), lse_m = lse_sub(cum_m1, cum_m0);
+            cum_t0 = cum_t1;
+            cum_m0 = cum_m1;
+            // prior term q(x_T | x_0) vs uniform (GMD:887)
+            const float cT = srT.log_1m_acp - logK;
+            const float p_hot = lae(0.0f + srT.log_acp, cT), p_cold = lae(MTK_LOG_TINY + srT.log_acp, cT);
+            for (int i = 0; i < Kk; ++i) {
+                const float qo = (i == ct) ? q_hot : q_cold;
+                const float lt = (((i == c0) ? e_hot : e_cold) + qo) - lse_t;
+                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae(lsm + s1.log_acp, ce);
+                const float lm = (ev + qo) - lse_m;
+                kl += expf(lt) * (lt - lm);
+                nll += expf((i == c0) ? 0.0f : MTK_LOG_TINY) * lm;
+                const float qT = (i == c0) ? p_hot : p_cold;
+                prior += expf(qT) * (qT + logK);
+            }
+        }
+        const float mask = (t == 0) ? 1.0f : 0.0f;
+        const float lt = mask * (-nll) + (1.0f - mask) * kl;
+        const float p_t = 1.0f / (float)T;
+        a.loss_multi[row] = (lt / p_t + prior) / (float)C;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// p_sample_step: a16 (GMD:358, 545, 323, 663) + a17 (GMD:810, 837, 852); t is uniform over the batch
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+    DevTables d;
+    int64_t B;
+    int t, first;
+    // fp32 coefficients of this t and the fp64 standard deviation exp(0.5 * model_log_variance[t])
+    float sqrt_recip, sqrt_recipm1, coef1, coef2, log_alpha, log_1m_alpha, log_acp_prev, log_1m_acp_prev;
+    double sigma;
+    const float* mo; int64_t mo_rs, mo_cs;
+    double* z;
+    int32_t* z_idx;
+    const void* noise; int noise_f64;
+    const float* u;
+    float* x_in; int64_t xi_rs, xi_cs;
+    uint64_t seed, row0;
+};
+
+__global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
+    const Staged s = stage_tables<false>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, S = a.d.S, t = a.t;
+    const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)t, stream_u = stream_n + 1u;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const float* mo = a.mo + row * a.mo_rs;
+        float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
+        for (int j = 0; j < Nn; ++j) {
+            const float eh = mo[j * a.mo_cs];
+            double* zp = a.z + (int64_t)j * a.B + row;
+            const double zj = *zp;
+            double nz;
+            if (a.noise) {
+                nz = a.noise_f64 ? reinterpret_cast<const double*>(a.noise)[row * Nn + j]
+                                 : (double)reinterpret_cast<const float*>(a.noise)[row * Nn + j];
+            } else {
+                nz = (double)mtk_philox_normal(a.seed, a.row0 + row, stream_n, j);
+            }
+            double mean;
+            if (a.first) {  // z is still fp32: torch forms the mean in fp32 (SURVEY finding 0.4)
+                const float zf = (float)zj;
+                const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
+                mean = (double)(a.coef1 * x0h + a.coef2 * zf);
+            } else {  // fp32 coefficient x fp64 state promotes; the eps term is an fp32 product
+                const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
+                mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+            }
+            const double mask = (t != 0) ? 1.0 : 0.0;
+            const double zn = mean + (mask * a.sigma) * nz;
+            *zp = zn;
+            if (xo) xo[j * a.xi_cs] = (float)zn;
+        }
+        double run = -INFINITY;
+        float cum0 = -INFINITY;
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const float logK = s.logK[k];
+            const int cz = a.z_idx[(int64_t)k * a.B + row];
+            const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+            const float cq = a.log_1m_alpha - logK;
+            const float q_hot = lae(0.0f + a.log_alpha, cq), q_cold = lae(MTK_LOG_TINY + a.log_alpha, cq);
+            const float ce = a.log_1m_acp_prev - logK;
+            float mx = -INFINITY;
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            float sum = 0.0f;
+            for (int i = 0; i < Kk; ++i) sum += expf(mc[i * a.mo_cs] - mx);
+            const float lsum = logf(sum);
+            for (int i = 0; i < Kk; ++i) {
+                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae(lsm + a.log_acp_prev, ce);
+                scan_push(run, ev + ((i == cz) ? q_hot : q_cold));
+            }
+            const float cum1 = (float)run;
+            const float lse = lse_sub(cum1, cum0);
+            cum0 = cum1;
+            float best = -INFINITY;
+            int arg = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae(lsm + a.log_acp_prev, ce);
+                const float logp = (ev + ((i == cz) ? q_hot : q_cold)) - lse;
+                const float uu = a.u ? a.u[row * S + o + i] : mtk_philox_uniform(a.seed, a.row0 + row, stream_u, o + i);
+                const float v = gumbel(uu) + logp;
+                if (v > best || i == 0) { best = v; arg = i; }
+            }
+            a.z_idx[(int64_t)k * a.B + row] = arg;
+            if (xo)
+                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
+    }
+}
+
+// sample() prologue (GMD:1392-1399)
+struct InitArgs {
+    DevTables d;
+    int64_t B;
+    const float* z0;
+    const float* u0;
+    double* z;
+    int32_t* z_idx;
+    float* x_in; int64_t xi_rs, xi_cs;
+    uint64_t seed, row0;
+};
+
+__global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
+    const Staged s = stage_tables<false>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        float* xo = a.x_in + row * a.xi_rs;
+        for (int j = 0; j < Nn; ++j) {
+            const float v = a.z0 ? a.z0[row * Nn + j] : mtk_philox_normal(a.seed, a.row0 + row, MTK_STREAM_Z0, j);
+            a.z[(int64_t)j * a.B + row] = (double)v;
+            xo[j * a.xi_cs] = v;
+        }
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            float best = -INFINITY;
+            int arg = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float uu = a.u0 ? a.u0[row * S + o + i] : mtk_philox_uniform(a.seed, a.row0 + row, MTK_STREAM_U0, o + i);
+                const float v = gumbel(uu) + 0.0f;
+                if (v > best || i == 0) { best = v; arg = i; }
+            }
+            a.z_idx[(int64_t)k * a.B + row] = arg;
+            for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
+    }
+}
+
+// sample() epilogue (GMD:1419-1423): [B, Nn + C] fp64 row-major
+__global__ __launch_bounds__(kBlock) void k_sample_decode(int64_t B, int Nn, int C, const double* z, const int32_t* z_idx,
+                                                          double* out) {
+    const int W = Nn + C;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < B * W; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = i / W;
+        const int c = (int)(i - row * W);
+        out[i] = (c < Nn) ? z[(int64_t)c * B + row] : (double)z_idx[(int64_t)(c - Nn) * B + row];
+    }
+}
+
+int grid_for(int64_t B) {
+    int64_t g = (B + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;  // 256 CUs x 8 resident workgroups; grid-stride covers the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+size_t lds_bytes(const mtk_ctx* c, bool rows) {
+    size_t b = rows ? (size_t)c->T * sizeof(SchedRow) : 0;
+    b += (((size_t)(c->C + 1) * 4 + 15) & ~(size_t)15) + (size_t)(c->C > 0 ? c->C : 1) * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+}  // namespace
+
+extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                            const float* u, float* x_in, int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed,
+                            uint64_t row0, mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null context");
+    if (B < 0 || !x0 || !t || !x_in) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
+    if (ctx->C > 0 && !xt_idx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: xt_idx is required when C > 0");
+    if (x0_ld < ctx->Nn + ctx->C) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: x0_ld %lld < Nn + C = %d", (long long)x0_ld, ctx->Nn + ctx->C);
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0};
+    const bool lds = ctx->T <= MTK_LDS_T_MAX;
+    auto k = lds ? k_q_sample<true> : k_q_sample<false>;
+    hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, int64_t mo_rs, int64_t mo_cs, const float* x0,
+                             int64_t x0_ld, const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi,
+                             float* loss_gauss, uint64_t seed, uint64_t row0, mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: null context");
+    if (B < 0 || !model_out || !t) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: null pointer or negative B");
+    if (loss_multi && ctx->C > 0 && (!x0 || !xt_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: x0 and xt_idx are required for the multinomial loss");
+    if (x0 && x0_ld < ctx->Nn + ctx->C) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: x0_ld too small");
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    LossArgs a{ctx->dev(), B, model_out, mo_rs, mo_cs, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, seed, row0};
+    const bool lds = ctx->T <= MTK_LDS_T_MAX;
+    auto k = lds ? k_loss_rows<true> : k_loss_rows<false>;
+    hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
+                                 int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64,
+                                 const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed,
+                                 uint64_t row0, mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: null context");
+    if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: t = %d outside [0, %d)", t, ctx->T);
+    if (B < 0 || !model_out || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: null pointer or negative B");
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    const int tp = t > 0 ? t - 1 : 0;
+    StepArgs a;
+    a.d = ctx->dev();
+    a.B = B; a.t = t; a.first = first_step;
+    a.sqrt_recip = (float)ctx->tab(MTK_TAB_SQRT_RECIP_ACP, t);
+    a.sqrt_recipm1 = (float)ctx->tab(MTK_TAB_SQRT_RECIPM1_ACP, t);
+    a.coef1 = (float)ctx->tab(MTK_TAB_POST_COEF1, t);
+    a.coef2 = (float)ctx->tab(MTK_TAB_POST_COEF2, t);
+    a.log_alpha = (float)ctx->tab(MTK_TAB_LOG_ALPHA, t);
+    a.log_1m_alpha = (float)ctx->tab(MTK_TAB_LOG_1M_ALPHA, t);
+    a.log_acp_prev = (float)ctx->tab(MTK_TAB_LOG_ACP, tp);
+    a.log_1m_acp_prev = (float)ctx->tab(MTK_TAB_LOG_1M_ACP, tp);
+    a.sigma = exp(0.5 * ctx->tab(MTK_TAB_MODEL_LOGVAR64, t));
+    a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
+    a.z = z; a.z_idx = z_idx; a.noise = noise; a.noise_f64 = noise_is_f64; a.u = u;
+    a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
+    hipLaunchKernelGGL(k_p_sample_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, double* z, int32_t* z_idx,
+                               float* x_in, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null context");
+    if (B < 0 || !x_in || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null pointer or negative B");
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    InitArgs a{ctx->dev(), B, z0, u0, z, z_idx, x_in, xi_rs, xi_cs, seed, row0};
+    hipLaunchKernelGGL(k_sample_init, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, double* sample,
+                                 mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_decode: null context");
+    if (B < 0 || !sample) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_decode: null pointer or negative B");
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sample_decode, dim3(grid_for(B * (ctx->Nn + ctx->C))), dim3(kBlock), 0, (hipStream_t)stream, B,
+                       ctx->Nn, ctx->C, z, z_idx, sample);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}

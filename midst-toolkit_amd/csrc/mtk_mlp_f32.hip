@@ -1,0 +1,321 @@
+// mtk_mlp_f32.hip — MLPDiffusion denoiser (MODEL:548-615), exact-fp32 path + weight ingestion.
+//
+// Layer-by-layer GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain per
+// output element), 128x128x32 workgroup tile, 4 waves as 2x2, each wave 2x2 tiles of 32x32.
+// This is the parity path (fp32 in, fp32 accumulate, fp32 out); the throughput path is the fused
+// bf16 kernel in mtk_mlp_bf16.hip.  Activations ping-pong through two context-owned buffers.
+#include <math.h>
+
+#include "mtk_common.h"
+
+int mtk_pack_fused(mtk_ctx* c, hipStream_t s);    // mtk_mlp_bf16.hip
+void mtk_free_fused(mtk_ctx* c);                  // mtk_mlp_bf16.hip
+int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                      float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16.hip
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+struct GemmArgs {
+    int64_t M;          // logical rows
+    int N, K;           // logical output / input widths
+    int Kpad;           // multiple of BK
+    const float* X; int64_t x_rs, x_cs;  // generic input (XGEN) or row-major with ld = x_rs (x_cs ignored)
+    const float* W; int ldw;             // [Npad][Kpad]
+    const float* bias;                   // [Npad]
+    const float* emb; int emb_ld;        // optional [T][emb_ld] gathered by t
+    const int64_t* tvec; int t_scalar;
+    int act;
+    float* Y; int64_t y_rs, y_cs;        // generic output (OGEN) or row-major with ld = y_rs
+};
+
+template <bool XGEN, bool OGEN>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[BM][LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN][LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    for (int k0 = 0; k0 < g.Kpad; k0 += BK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q, r = idx >> 3, c = (idx & 7) * 4;
+            float4 v;
+            if (XGEN) {
+                const int64_t row = m0 + r;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = k0 + c + j;
+                    e[j] = (row < g.M && kk < g.K) ? g.X[row * g.x_rs + (int64_t)kk * g.x_cs] : 0.0f;
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            } else {
+                v = *reinterpret_cast<const float4*>(g.X + (m0 + r) * g.x_rs + k0 + c);
+            }
+            *reinterpret_cast<float4*>(&As[r][c]) = v;
+            *reinterpret_cast<float4*>(&Bs[r][c]) = *reinterpret_cast<const float4*>(g.W + (int64_t)(n0 + r) * g.ldw + k0 + c);
+        }
+        __syncthreads();
+        // lane (li, hh) owns k in [16 hh, 16 hh + 16) of this K block for both operands
+        float a[2][16], b[2][16];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&As[wr * 64 + mt * 32 + li][16 * hh + 4 * q]);
+                a[mt][4 * q] = v.x; a[mt][4 * q + 1] = v.y; a[mt][4 * q + 2] = v.z; a[mt][4 * q + 3] = v.w;
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&Bs[wc * 64 + nt * 32 + li][16 * hh + 4 * q]);
+                b[nt][4 * q] = v.x; b[nt][4 * q + 1] = v.y; b[nt][4 * q + 2] = v.z; b[nt][4 * q + 3] = v.w;
+            }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wc * 64 + nt * 32 + li;
+            const float bias = g.bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[mt][nt][r] + bias;
+                if (g.emb) {
+                    const int tr = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
+                    v += g.emb[(int64_t)tr * g.emb_ld + n];
+                }
+                if (g.act == ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (g.act == ACT_SILU) v = v / (1.0f + expf(-v));
+                if (OGEN) {
+                    if (row < g.M && n < g.N) g.Y[row * g.y_rs + (int64_t)n * g.y_cs] = v;
+                } else {
+                    g.Y[row * g.y_rs + n] = v;
+                }
+            }
+        }
+}
+
+__global__ void k_pad_copy(float* dst, int rows_pad, int cols_pad, const float* src, int rows, int cols) {
+    const int64_t n = (int64_t)rows_pad * cols_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+        dst[i] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.0f;
+    }
+}
+
+// MODEL:123-144: [cos(t f_i), sin(t f_i)] (+ a zero column when dim is odd), rows padded to BM
+__global__ void k_sinusoid(float* dst, int Tpad, int ld, int T, int dim, const float* freqs) {
+    const int half = dim / 2;
+    const int64_t n = (int64_t)Tpad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / ld), c = (int)(i % ld);
+        float v = 0.0f;
+        if (t < T && c < 2 * half) {
+            const float arg = (float)t * freqs[c < half ? c : c - half];
+            v = c < half ? cosf(arg) : sinf(arg);
+        }
+        dst[i] = v;
+    }
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+void free_layer(MlpLayer& l) {
+    if (l.w32) (void)hipFree(l.w32);
+    if (l.b32) (void)hipFree(l.b32);
+    l = MlpLayer();
+}
+
+int make_layer(MlpLayer& l, int in, int out, int in_pad, const float* W, const float* b, hipStream_t s) {
+    free_layer(l);
+    l.in = in;
+    l.out = out;
+    l.in_pad = in_pad;
+    l.out_pad = round_up(out, BN);
+    MTK_HIP(hipMalloc(&l.w32, sizeof(float) * (size_t)l.out_pad * l.in_pad));
+    MTK_HIP(hipMalloc(&l.b32, sizeof(float) * (size_t)l.out_pad));
+    hipLaunchKernelGGL(k_pad_copy, dim3(256), dim3(256), 0, s, l.w32, l.out_pad, l.in_pad, W, out, in);
+    hipLaunchKernelGGL(k_pad_copy, dim3(4), dim3(256), 0, s, l.b32, 1, l.out_pad, b, 1, out);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+template <bool XGEN, bool OGEN>
+int launch_gemm(const GemmArgs& g, int64_t Mpad, int Npad, hipStream_t s) {
+    hipLaunchKernelGGL((k_gemm_f32<XGEN, OGEN>), dim3((unsigned)(Mpad / BM), (unsigned)(Npad / BN)), dim3(256), 0, s, g);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+}  // namespace
+
+void mtk_free_mlp(mtk_ctx* c) {
+    free_layer(c->proj);
+    free_layer(c->temb0);
+    free_layer(c->temb2);
+    free_layer(c->head);
+    for (auto& l : c->blocks) free_layer(l);
+    c->blocks.clear();
+    if (c->d_emb) (void)hipFree(c->d_emb);
+    c->d_emb = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (c->ws[i]) (void)hipFree(c->ws[i]);
+        c->ws[i] = nullptr;
+    }
+    c->ws_elems = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (c->tf_ws[i]) (void)hipFree(c->tf_ws[i]);
+        c->tf_ws[i] = nullptr;
+    }
+    c->tf_ws_elems = 0;
+    mtk_free_fused(c);
+    c->have_weights = false;
+}
+
+extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims_host, const float* const* W,
+                                   const float* const* b, const float* freqs_host, mtk_stream stream) {
+    if (!c || !dims_host || !W || !b || !freqs_host) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: null argument");
+    if (n_hidden < 1 || n_hidden > 16) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_set_weights: n_hidden = %d not in [1, 16]", n_hidden);
+    const int D = dims_host[0], dim_t = dims_host[1];
+    if (D != c->D) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: denoiser width %d != Nn + S = %d", D, c->D);
+    if (dim_t < 2 || dim_t > 1024) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_set_weights: dim_t = %d", dim_t);
+    for (int i = 0; i < n_hidden; ++i)
+        if (dims_host[2 + i] < 1 || dims_host[2 + i] > 8192) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_set_weights: hidden[%d] = %d", i, dims_host[2 + i]);
+    for (int i = 0; i < n_hidden + 4; ++i)
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: W[%d] or b[%d] is null", i, i);
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    // the previous image may still be in use by work queued on this stream
+    MTK_HIP(hipStreamSynchronize(s));
+    mtk_free_mlp(c);
+    c->dim_t = dim_t;
+    c->n_hidden = n_hidden;
+    c->hidden.assign(dims_host + 2, dims_host + 2 + n_hidden);
+    const int tpad = round_up(dim_t, BN);
+    int rc;
+    if ((rc = make_layer(c->proj, D, dim_t, round_up(D, BK), W[0], b[0], s))) return rc;
+    if ((rc = make_layer(c->temb0, dim_t, dim_t, tpad, W[1], b[1], s))) return rc;
+    if ((rc = make_layer(c->temb2, dim_t, dim_t, tpad, W[2], b[2], s))) return rc;
+    c->blocks.resize(n_hidden);
+    int prev = dim_t, prev_pad = tpad;
+    for (int i = 0; i < n_hidden; ++i) {
+        if ((rc = make_layer(c->blocks[i], prev, c->hidden[i], prev_pad, W[3 + i], b[3 + i], s))) return rc;
+        prev = c->hidden[i];
+        prev_pad = c->blocks[i].out_pad;
+    }
+    if ((rc = make_layer(c->head, prev, D, prev_pad, W[3 + n_hidden], b[3 + n_hidden], s))) return rc;
+
+    // time-embedding table emb[t] = Linear2(SiLU(Linear0(sinusoid(t))))  (MODEL:608)
+    const int Tpad = round_up(c->T, BM);
+    float *d_freq = nullptr, *e0 = nullptr, *e1 = nullptr;
+    MTK_HIP(hipMalloc(&d_freq, sizeof(float) * (dim_t / 2)));
+    MTK_HIP(hipMalloc(&e0, sizeof(float) * (size_t)Tpad * tpad));
+    MTK_HIP(hipMalloc(&e1, sizeof(float) * (size_t)Tpad * tpad));
+    MTK_HIP(hipMalloc(&c->d_emb, sizeof(float) * (size_t)Tpad * tpad));
+    c->emb_ld = tpad;
+    MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (dim_t / 2), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sinusoid, dim3(256), dim3(256), 0, s, e0, Tpad, tpad, c->T, dim_t, d_freq);
+    GemmArgs g{};
+    g.M = Tpad; g.N = dim_t; g.K = dim_t; g.Kpad = tpad;
+    g.X = e0; g.x_rs = tpad; g.W = c->temb0.w32; g.ldw = tpad; g.bias = c->temb0.b32;
+    g.act = ACT_SILU; g.Y = e1; g.y_rs = tpad;
+    if ((rc = launch_gemm<false, false>(g, Tpad, tpad, s))) return rc;
+    g.X = e1; g.W = c->temb2.w32; g.bias = c->temb2.b32; g.act = ACT_NONE; g.Y = c->d_emb;
+    if ((rc = launch_gemm<false, false>(g, Tpad, tpad, s))) return rc;
+    MTK_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_freq);
+    (void)hipFree(e0);
+    (void)hipFree(e1);
+    c->have_weights = true;
+    return mtk_pack_fused(c, s);
+}
+
+// Exact-fp32 forward for `B` rows starting at x / out.
+static int forward_f32(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                       float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
+    const int64_t chunk = 65536;
+    int maxpad = c->proj.out_pad;
+    for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
+    const int64_t need_rows = (B < chunk ? (B + BM - 1) / BM * BM : chunk);
+    const size_t need = (size_t)need_rows * maxpad;
+    if (need > c->ws_elems) {
+        MTK_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < 2; ++i) {
+            if (c->ws[i]) (void)hipFree(c->ws[i]);
+            c->ws[i] = nullptr;
+            MTK_HIP(hipMalloc(&c->ws[i], sizeof(float) * need));
+        }
+        c->ws_elems = need;
+    }
+    for (int64_t r0 = 0; r0 < B; r0 += chunk) {
+        const int64_t M = (B - r0 < chunk) ? B - r0 : chunk;
+        const int64_t Mpad = (M + BM - 1) / BM * BM;
+        int rc;
+        GemmArgs g{};
+        g.M = M; g.N = c->proj.out; g.K = c->proj.in; g.Kpad = c->proj.in_pad;
+        g.X = x + r0 * x_rs; g.x_rs = x_rs; g.x_cs = x_cs;
+        g.W = c->proj.w32; g.ldw = c->proj.in_pad; g.bias = c->proj.b32;
+        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar;
+        g.act = ACT_NONE; g.Y = c->ws[0]; g.y_rs = c->proj.out_pad;
+        if ((rc = launch_gemm<true, false>(g, Mpad, c->proj.out_pad, s))) return rc;
+        int cur = 0;
+        for (auto& l : c->blocks) {
+            GemmArgs h{};
+            h.M = M; h.N = l.out; h.K = l.in; h.Kpad = l.in_pad;
+            h.X = c->ws[cur]; h.x_rs = l.in_pad; h.W = l.w32; h.ldw = l.in_pad; h.bias = l.b32;
+            h.act = ACT_RELU; h.Y = c->ws[cur ^ 1]; h.y_rs = l.out_pad;
+            if ((rc = launch_gemm<false, false>(h, Mpad, l.out_pad, s))) return rc;
+            cur ^= 1;
+        }
+        GemmArgs h{};
+        h.M = M; h.N = c->head.out; h.K = c->head.in; h.Kpad = c->head.in_pad;
+        h.X = c->ws[cur]; h.x_rs = c->head.in_pad; h.W = c->head.w32; h.ldw = c->head.in_pad; h.bias = c->head.b32;
+        h.act = ACT_NONE; h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
+        if ((rc = launch_gemm<false, true>(h, Mpad, c->head.out_pad, s))) return rc;
+    }
+    return MTK_OK;
+}
+
+extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
+                               int t_scalar, float* out, int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: null context");
+    if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward: call mtk_mlp_set_weights first");
+    if (B < 0 || !x || !out) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: null pointer or negative B");
+    if (!t && (t_scalar < 0 || t_scalar >= c->T)) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: t_scalar = %d outside [0, %d)", t_scalar, c->T);
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(c->device));
+    if (precision == MTK_PREC_FP32) return forward_f32(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
+    if (precision == MTK_PREC_BF16) {
+        if (!c->fused_ok) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward: the fused bf16 kernel does not support this denoiser shape");
+        return mtk_fused_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
+    }
+    MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward: unknown precision %d", precision);
+}

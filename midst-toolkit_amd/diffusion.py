@@ -1,0 +1,294 @@
+"""Drop-in for the reference's ``GaussianMultinomialDiffusion`` (GMD:155) on MI355X.
+
+Same constructor, buffers (14 registered + 4 plain attributes), method names and return types on
+the hot path: ``mixed_loss`` (GMD:1013), ``gaussian_q_sample`` (GMD:302), ``_gaussian_loss``
+(GMD:505), ``sample`` (GMD:1370), ``sample_all`` (GMD:1426).  All arithmetic runs in
+libmtk_hip.so; this file only draws random numbers in the reference's order (so a seeded torch
+generator reproduces the reference's injected noise) and moves pointers.
+
+Extra, not in the reference: ``mixed_loss_rows`` returns the per-record losses whose means
+``mixed_loss`` returns; ``rng="philox"`` draws inside the kernels instead of through torch.
+"""
+from __future__ import annotations
+
+from enum import Enum
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import schedule
+from .engine import Engine
+from .schedule import SchedulerType
+
+
+class GaussianLossType(Enum):
+    MSE = "mse"
+    KL = "kl"
+
+
+class GaussianParametrization(Enum):
+    EPS = "eps"
+    X0 = "x0"
+
+
+class Parametrization(Enum):
+    X0 = "x0"
+    DIRECT = "direct"
+
+
+class FoundNaNsError(BaseException):
+    """DU:305."""
+
+    def __init__(self, message: str = "Found NANs during sampling."):
+        super().__init__(message)
+
+
+def _default_device() -> torch.device:
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class GaussianMultinomialDiffusion(torch.nn.Module):
+    def __init__(
+        self,
+        num_classes: np.ndarray,
+        num_numerical_features: int,
+        denoise_fn: torch.nn.Module,
+        num_timesteps: int = 1000,
+        gaussian_loss_type: GaussianLossType = GaussianLossType.MSE,
+        gaussian_parametrization: GaussianParametrization = GaussianParametrization.EPS,
+        parametrization: Parametrization = Parametrization.X0,
+        scheduler_type: SchedulerType = SchedulerType.COSINE,
+        device: torch.device | None = None,
+    ):
+        super().__init__()
+        device = torch.device(device) if device is not None else _default_device()
+        num_classes = np.asarray(num_classes)
+        # the reference raises ValueError lazily for these enums (GMD:408, 543, 832); do it up front
+        if getattr(gaussian_loss_type, "value", None) != "mse":
+            raise ValueError(f"Unsupported Gaussian loss type: {gaussian_loss_type}")
+        if getattr(gaussian_parametrization, "value", None) != "eps":
+            raise ValueError(f"Unsupported Gaussian parametrization: {gaussian_parametrization}")
+        if getattr(parametrization, "value", None) != "x0":
+            raise ValueError(f"Unsupported parametrization: {parametrization}")
+        scheduler_type = SchedulerType(getattr(scheduler_type, "value", scheduler_type))
+
+        self.num_numerical_features = num_numerical_features
+        self.num_classes = num_classes
+        self.num_classes_expanded = torch.from_numpy(
+            np.concatenate([num_classes[i].repeat(num_classes[i]) for i in range(len(num_classes))])
+        ).to(device)
+        self.slices_for_classes = [np.arange(self.num_classes[0])]
+        offsets = np.cumsum(self.num_classes)
+        for i in range(1, len(offsets)):
+            self.slices_for_classes.append(np.arange(offsets[i - 1], offsets[i]))
+        self.offsets = torch.from_numpy(np.append([0], offsets)).to(device)
+
+        self._denoise_fn = denoise_fn
+        self.gaussian_loss_type = gaussian_loss_type
+        self.gaussian_parametrization = gaussian_parametrization
+        self.num_timesteps = num_timesteps
+        self.parametrization = parametrization
+        self.scheduler_type = scheduler_type
+        self.device = device
+
+        buffers = schedule.buffer_values(scheduler_type, num_timesteps)
+        post = schedule.posterior_values(buffers)
+        self.posterior_variance = post["posterior_variance"]  # fp64, never cast (GMD:223)
+        self.posterior_log_variance_clipped = post["posterior_log_variance_clipped"].to(device)
+        self.posterior_mean_coef1 = post["posterior_mean_coef1"].to(device)
+        self.posterior_mean_coef2 = post["posterior_mean_coef2"].to(device)
+        self._host_tables = {k: v.float() for k, v in buffers.items()}
+        self._host_tables.update({k: post[k] for k in ("posterior_mean_coef1", "posterior_mean_coef2", "model_log_variance")})
+        for key, value in buffers.items():
+            self.register_buffer(key, value.float().to(device))
+
+        self.rng = "torch"  # "torch": draw like the reference does; "philox": draw inside the kernels
+        self.precision = getattr(denoise_fn, "precision", "fp32")
+        self._engine: Engine | None = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def _has_cat(self) -> bool:
+        return len(self.num_classes) > 0 and int(self.num_classes[0]) != 0
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        # follow .to(device) like the reference's buffers do
+        self.device = self.alphas.device
+        for name in ("posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2", "num_classes_expanded", "offsets"):
+            setattr(self, name, fn(getattr(self, name)))
+        return out
+
+    def engine(self) -> Engine:
+        dev = self.alphas.device
+        if self._engine is None or self._engine.device != dev:
+            self._engine = Engine(dev, self.num_timesteps, self.num_numerical_features, self.num_classes, self._host_tables)
+            if hasattr(self._denoise_fn, "attach_engine"):
+                self._denoise_fn.attach_engine(self._engine)
+        if hasattr(self._denoise_fn, "sync_weights"):
+            self._denoise_fn.sync_weights()
+        return self._engine
+
+    def _denoise_cm(self, eng: Engine, x_in: Tensor, t, B: int, out: Tensor) -> None:
+        """Denoiser on the column-major [D][B] intermediates."""
+        if not hasattr(self._denoise_fn, "sync_weights"):
+            raise TypeError("the MI355X path needs midst_toolkit_amd.MLPDiffusion as denoise_fn")
+        eng.mlp_forward(x_in, t, out=out, precision=self.precision, x_strides=(1, B), out_strides=(1, B), B=B)
+
+    # ------------------------------------------------------------------ Gaussian pieces used by callers (TF:86-93)
+    def gaussian_q_sample(self, features_start: Tensor, timestep: Tensor, noise: Tensor | None = None) -> Tensor:
+        """GMD:302 via mtk_q_sample with the categorical block switched off."""
+        if noise is None:
+            noise = torch.randn_like(features_start)
+        assert noise.shape == features_start.shape
+        x = features_start.float().contiguous()
+        B, n = x.shape
+        eng = self._aux_engine(n)
+        out = torch.empty_like(x)
+        eng.q_sample(x, timestep.to(x.device, torch.int64).contiguous(), noise.float().contiguous(), None, out, (n, 1), None)
+        return out
+
+    def _gaussian_loss(self, model_out: Tensor, features_start: Tensor, features_timestep: Tensor, timestep: Tensor,
+                       noise: Tensor, model_kwargs: dict[str, Any] | None = None) -> Tensor:
+        """GMD:505, MSE branch: mean_d (noise - model_out)^2 per record."""
+        mo = model_out.float().contiguous()
+        B, n = mo.shape
+        eng = self._aux_engine(n)
+        out = torch.empty((B,), dtype=torch.float32, device=mo.device)
+        eng.loss_rows(mo, (n, 1), None, None, noise.float().contiguous(), timestep.to(mo.device, torch.int64).contiguous(), None, out)
+        return out
+
+    def _aux_engine(self, n: int) -> Engine:
+        """Numeric-only context of width n for the stand-alone Gaussian helpers."""
+        cache = self.__dict__.setdefault("_aux", {})
+        dev = self.alphas.device
+        key = (n, str(dev))
+        if key not in cache:
+            cache[key] = Engine(dev, self.num_timesteps, n, [0], self._host_tables)
+        return cache[key]
+
+    # ------------------------------------------------------------------ loss entry point
+    def _draw_loss_noise(self, features: Tensor):
+        """The reference's draw order (SURVEY finding 0.5): randint → randn_like → per-column rand_like."""
+        B = features.shape[0]
+        dev = features.device
+        t = torch.randint(0, self.num_timesteps, (B,), device=dev).long()
+        Nn = self.num_numerical_features
+        eps = torch.randn_like(features[:, :Nn]) if Nn > 0 else None
+        u = None
+        if self._has_cat and features.shape[1] - Nn > 0:
+            u = torch.cat([torch.rand((B, int(k)), device=dev, dtype=torch.float32) for k in self.num_classes], dim=1)
+        return t, eps, u
+
+    @torch.no_grad()
+    def mixed_loss_rows(self, features: Tensor, timestep: Tensor | None = None, noise: Tensor | None = None,
+                        uniform: Tensor | None = None, seed: int = 0, row0: int = 0):
+        """Per-record (multinomial / C, gaussian) losses.  With ``timestep``/``noise``/``uniform`` given
+        they are injected; otherwise drawn per ``self.rng``.  Returns 1-element zero tensors on CPU
+        for an absent side, exactly like GMD:1047-1048."""
+        if not features.is_cuda:
+            raise RuntimeError("mixed_loss: midst_toolkit_amd has no CPU path; move the model and batch to the MI355X")
+        eng = self.engine()
+        x0 = features.float().contiguous()
+        B = x0.shape[0]
+        Nn, C, D = eng.Nn, eng.C, eng.D
+        dev = x0.device
+        if timestep is None:
+            if self.rng == "torch":
+                timestep, noise, uniform = self._draw_loss_noise(x0)
+            else:
+                timestep = torch.randint(0, self.num_timesteps, (B,), device=dev).long()
+                seed = int(torch.randint(0, 2**62, (1,)).item()) if seed == 0 else seed
+        t = timestep.to(dev, torch.int64).contiguous()
+        eps = noise.float().contiguous() if noise is not None else None
+        u = uniform.float().contiguous() if uniform is not None else None
+        x_in = torch.empty((D, B), dtype=torch.float32, device=dev)
+        out = torch.empty((D, B), dtype=torch.float32, device=dev)
+        xt_idx = torch.empty((max(C, 1), B), dtype=torch.int32, device=dev)
+        eng.q_sample(x0, t, eps, u, x_in, (1, B), xt_idx, seed, row0)
+        self._denoise_cm(eng, x_in, t, B, out)
+        lm = torch.empty((B,), dtype=torch.float32, device=dev) if C > 0 else None
+        lg = torch.empty((B,), dtype=torch.float32, device=dev) if Nn > 0 else None
+        eng.loss_rows(out, (1, B), x0, xt_idx, eps, t, lm, lg, seed, row0)
+        zero = torch.zeros((1,)).float()
+        return (lm if lm is not None else zero), (lg if lg is not None else zero)
+
+    def mixed_loss(self, features: Tensor, outputs: dict[str, Tensor]) -> tuple[Tensor, Tensor]:
+        """GMD:1013: (mean multinomial loss / C, mean Gaussian loss).  ``outputs['y']`` is accepted
+        and ignored like the reference's denoiser ignores it (MODEL:610)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "mixed_loss with autograd: the HIP backward (SURVEY section 8 row a19) is not built yet; "
+                "call under torch.no_grad() for loss evaluation / scoring"
+            )
+        lm, lg = self.mixed_loss_rows(features)
+        return lm.mean(), lg.mean()
+
+    # ------------------------------------------------------------------ reverse chain
+    @torch.no_grad()
+    def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
+               conditioning_function=None, _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+        """GMD:1370.  Returns ([B, Nn + C] fp64 on CPU, {"y": labels})."""
+        if conditioning_function is not None:
+            raise NotImplementedError("classifier guidance (conditional sampling, SURVEY section 8f rank 2) is not on the MI355X path yet")
+        eng = self.engine()
+        dev = eng.device
+        B, Nn, C, D, S, T = batch_size, eng.Nn, eng.C, eng.D, eng.S, self.num_timesteps
+        inj = _injected
+        philox = self.rng == "philox" and inj is None
+        seed = int(torch.randint(1, 2**62, (1,)).item()) if philox else 0
+
+        def draw_u():
+            return torch.cat([torch.rand((B, int(k)), device=dev, dtype=torch.float32) for k in self.num_classes], dim=1)
+
+        z0 = u0 = None
+        if inj is not None:
+            z0, u0 = inj["z0"], inj.get("u0")
+        elif not philox:
+            z0 = torch.randn((B, Nn), device=dev)
+            u0 = draw_u() if C else None
+        z = torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev)
+        z_idx = torch.empty((max(C, 1), B), dtype=torch.int32, device=dev)
+        x_in = torch.empty((D, B), dtype=torch.float32, device=dev)
+        out = torch.empty((D, B), dtype=torch.float32, device=dev)
+        eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed)
+        if inj is not None and "y" in inj:
+            target = inj["y"]
+        else:
+            target = torch.multinomial(target_dist, num_samples=B, replacement=True)
+        outputs = {"y": target.long().to(dev)}
+        for i, t in enumerate(reversed(range(T))):
+            self._denoise_cm(eng, x_in, t, B, out)
+            n = u = None
+            if inj is not None:
+                n = inj["noise"][i] if Nn else None
+                u = inj["u"][i] if C else None
+            elif not philox:
+                if Nn:
+                    n = torch.randn((B, Nn), device=dev, dtype=torch.float32 if i == 0 else torch.float64)
+                u = draw_u() if C else None
+            eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed)
+        sample = torch.empty((B, Nn + C), dtype=torch.float64, device=dev)
+        eng.sample_decode(B, z, z_idx, sample)
+        return sample.cpu(), outputs
+
+    def sample_all(self, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False,
+                   model_kwargs: dict[str, Any] | None = None, conditioning_function=None) -> tuple[Tensor, Tensor]:
+        """GMD:1426."""
+        if ddim:
+            raise NotImplementedError("DDIM sampling (SURVEY section 8f rank 4) is not on the MI355X path")
+        all_targets, all_samples = [], []
+        num_generated = 0
+        while num_generated < num_samples:
+            sample, outputs = self.sample(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function)
+            mask_nan = torch.any(sample.isnan(), dim=1)
+            sample = sample[~mask_nan]
+            outputs["y"] = outputs["y"].cpu()[~mask_nan]
+            all_samples.append(sample)
+            all_targets.append(outputs["y"])
+            if sample.shape[0] != batch_size:
+                raise FoundNaNsError
+            num_generated += sample.shape[0]
+        return torch.cat(all_samples, dim=0)[:num_samples], torch.cat(all_targets, dim=0)[:num_samples]

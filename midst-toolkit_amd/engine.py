@@ -1,0 +1,130 @@
+"""Thin object wrapper over an ``mtk_ctx`` (include/mtk.h).  Tensors in, tensors out; all compute
+is enqueued on torch's current stream by libmtk_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PREC_BF16, PREC_FP32, check, ptr, require_cuda
+
+PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16}
+
+
+class Engine:
+    """One device context: schedule tables + categorical layout (+ packed denoiser weights)."""
+
+    def __init__(self, device: torch.device, T: int, Nn: int, K, tables: dict[str, torch.Tensor]):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"midst_toolkit_amd needs an MI355X (ROCm 'cuda') device, got {device}")
+        self.device = device
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        self.T, self.Nn = int(T), int(Nn)
+        K = np.asarray(K, dtype=np.int64).reshape(-1)
+        self.K = K if (len(K) and int(K[0]) != 0) else np.zeros((0,), dtype=np.int64)
+        self.C = len(self.K)
+        self.S = int(self.K.sum())
+        self.D = self.Nn + self.S
+        tab = np.stack([tables[name].double().cpu().numpy() for name in _lib.TABLE_ORDER]).astype(np.float64)
+        assert tab.shape == (_lib.NTAB, self.T), tab.shape
+        tab = np.ascontiguousarray(tab)
+        k32 = np.ascontiguousarray(self.K.astype(np.int32))
+        # log K exactly as the reference forms it: torch.log of an int64 tensor → fp32 (GMD:739)
+        logk = np.ascontiguousarray(torch.log(torch.from_numpy(self.K)).numpy().astype(np.float32)) if self.C else np.zeros(1, np.float32)
+        handle = C.c_void_p()
+        check(_lib.lib().mtk_ctx_create(self.index, self.T, self.Nn, self.C, k32.ctypes.data if self.C else None,
+                                        logk.ctypes.data if self.C else None, tab.ctypes.data, C.byref(handle)))
+        self._h = handle
+        self._weights_key = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().mtk_ctx_destroy(h)
+            except Exception:
+                pass
+
+    def _stream(self):
+        return _lib.stream_handle(self.device)
+
+    # ------------------------------------------------------------------ denoiser
+    def set_weights(self, weights: list[tuple[torch.Tensor, torch.Tensor]], dims: list[int], freqs: torch.Tensor) -> None:
+        """weights: [(W, b)] in the order proj, temb.0, temb.2, blocks..., head (fp32, on device)."""
+        n_hidden = len(weights) - 4
+        keep = []
+        for W, b in weights:
+            require_cuda(W, "set_weights")
+            keep += [W.detach().float().contiguous(), b.detach().float().contiguous()]
+        Wp = (C.c_void_p * len(weights))(*[keep[2 * i].data_ptr() for i in range(len(weights))])
+        bp = (C.c_void_p * len(weights))(*[keep[2 * i + 1].data_ptr() for i in range(len(weights))])
+        d = np.ascontiguousarray(np.asarray(dims, dtype=np.int32))
+        f = np.ascontiguousarray(freqs.detach().cpu().numpy().astype(np.float32))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_mlp_set_weights(self._h, n_hidden, d.ctypes.data, Wp, bp, f.ctypes.data, self._stream()))
+
+    def mlp_forward(self, x: torch.Tensor, t, out: torch.Tensor | None = None, precision: str = "fp32",
+                    x_strides=None, out_strides=None, B: int | None = None) -> torch.Tensor:
+        """x: [B, D] fp32 (any strides).  t: int64 [B] tensor or a Python int."""
+        require_cuda(x, "mlp_forward")
+        if B is None:
+            B = x.shape[0]
+        xs = x_strides if x_strides is not None else (x.stride(0), x.stride(1))
+        if out is None:
+            out = torch.empty((B, self.D), dtype=torch.float32, device=x.device)
+        os_ = out_strides if out_strides is not None else (out.stride(0), out.stride(1))
+        tv, ts = (t, 0) if isinstance(t, torch.Tensor) else (None, int(t))
+        if tv is not None:
+            assert tv.dtype == torch.int64 and tv.is_contiguous() and tv.numel() == B
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_mlp_forward(self._h, B, ptr(x), xs[0], xs[1], ptr(tv), ts, ptr(out), os_[0], os_[1],
+                                             PRECISIONS[precision], self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ loss side
+    def q_sample(self, x0, t, eps, u, x_in, xi_strides, xt_idx, seed=0, row0=0):
+        B = x0.shape[0]
+        assert x0.dtype == torch.float32 and x0.stride(1) == 1 and t.dtype == torch.int64
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_q_sample(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), ptr(x_in), xi_strides[0],
+                                          xi_strides[1], ptr(xt_idx), seed, row0, self._stream()))
+
+    def loss_rows(self, model_out, mo_strides, x0, xt_idx, eps, t, loss_multi, loss_gauss, seed=0, row0=0):
+        B = t.shape[0]
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_loss_rows(self._h, B, ptr(model_out), mo_strides[0], mo_strides[1], ptr(x0),
+                                           x0.stride(0) if x0 is not None else 0, ptr(xt_idx), ptr(eps), ptr(t), ptr(loss_multi),
+                                           ptr(loss_gauss), seed, row0, self._stream()))
+
+    def tf_score(self, x: torch.Tensor, noise: torch.Tensor, t_list, add_t: int = 0, precision: str = "fp32",
+                 out: torch.Tensor | None = None) -> torch.Tensor:
+        require_cuda(x, "tf_score")
+        B, P = x.shape[0], noise.shape[0]
+        assert x.dtype == torch.float32 and x.stride(1) == 1 and noise.is_contiguous() and noise.shape[1] == self.Nn
+        tl = np.ascontiguousarray(np.asarray(t_list, dtype=np.int32))
+        if out is None:
+            out = torch.empty((len(tl), B, P), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_tf_score(self._h, B, P, ptr(x), x.stride(0), ptr(noise), len(tl), tl.ctypes.data, add_t, ptr(out),
+                                          PRECISIONS[precision], self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ reverse chain
+    def sample_init(self, B, z0, u0, z, z_idx, x_in, xi_strides, seed=0, row0=0):
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_sample_init(self._h, B, ptr(z0), ptr(u0), ptr(z), ptr(z_idx), ptr(x_in), xi_strides[0], xi_strides[1],
+                                             seed, row0, self._stream()))
+
+    def p_sample_step(self, B, t, first, model_out, mo_strides, z, z_idx, noise, u, x_in_next, xi_strides, seed=0, row0=0):
+        nf64 = int(noise is not None and noise.dtype == torch.float64)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_p_sample_step(self._h, B, int(t), int(first), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z),
+                                               ptr(z_idx), ptr(noise), nf64, ptr(u), ptr(x_in_next), xi_strides[0], xi_strides[1],
+                                               seed, row0, self._stream()))
+
+    def sample_decode(self, B, z, z_idx, out):
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_sample_decode(self._h, B, ptr(z), ptr(z_idx), ptr(out), self._stream()))

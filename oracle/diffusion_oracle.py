@@ -367,3 +367,34 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
         if C:
             z_idx = multinomial_p_step(s, K, out[:, Nn:], z_idx, t, us[i])
     return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z
+
+
+# --------------------------------------------------------------------------- conditioning of a11
+def multinomial_loss_floor(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0: torch.Tensor, xt_idx: torch.Tensor,
+                           t: torch.Tensor, ulp: float = 2.0 ** -23) -> torch.Tensor:
+    """Per-record absolute uncertainty of the reference's OWN multinomial loss under a one-ulp change
+    of the fp32 ``exp`` inside ``log_sub_exp`` (DU:250-265).
+
+    The block normaliser is log(e^{cum_end - m} - e^{cum_start - m}) + m: a difference of two numbers
+    close to 1 whenever the block holds a small share of the cumulative mass.  Its absolute error is
+    ulp * kappa with kappa = (cumulative mass up to the block's end) / (block mass).  The KL/NLL
+    term inherits it once per block and per posterior (true and model), and the row loss scales it by
+    1/p_t = T and 1/C.  torch-CPU evaluates that exp with a closed-source MKL VML routine, so no
+    other implementation (the reference on a GPU included) can be expected to agree below this."""
+    C = len(K)
+    logK = log_k_expanded(K)
+    off = torch.from_numpy(offsets_of(K))
+    lx0 = log_onehot(x0[:, Nn:].long(), K)
+    lxt = log_onehot(xt_idx, K)
+
+    def kappa_sum(log_start):
+        ev = q_pred(s, log_start, torch.clamp(t - 1, min=0), logK)
+        ev = torch.where((t == 0)[:, None], log_start, ev)
+        un = (ev + q_pred_one(s, lxt, t, logK)).double()
+        cum = torch.logcumsumexp(F.pad(un, [1, 0, 0, 0], value=-float("inf")), dim=-1)
+        hi, lo = cum[:, off[1:]], cum[:, off[:-1]]
+        blk = hi + torch.log1p(-torch.exp(lo - hi))
+        return torch.exp(hi - blk).sum(dim=1)
+
+    kap = kappa_sum(lx0) + kappa_sum(block_log_softmax(model_out[:, Nn:], K))
+    return (s.T / C) * ulp * kap

@@ -1,0 +1,272 @@
+"""GPU: the HIP path (through the C ABI) against the oracle and the reference's golden vectors.
+
+Bars (DESIGN.md "Parity"):
+  * numeric noising, Gaussian loss, TF scores, denoiser (fp32 mode), fp64 reverse state: <= 1e-4 relative
+    (measured ~1e-6);
+  * categorical draws: identical to the reference given the same uniforms, except Gumbel near-ties
+    (the reference's own top-2 margin below TIE_MARGIN), which must be rarer than 1e-3 of decisions;
+  * multinomial loss: batch mean <= 1e-4 relative; per record |d| <= 1e-4 |ref| + 2 * conditioning floor
+    (tests/test_conditioning.py shows why a plain per-record 1e-4 is not well-posed).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_oracle as orc
+from tests.helpers import CASES, case_params, load_case, tt
+
+pytestmark = pytest.mark.gpu
+TIE_MARGIN = 2e-5
+RTOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def build(c, precision="fp32", T=None):
+    import midst_toolkit_amd as mtk
+
+    dp = mtk.DiffusionParameters(list(c["d_layers"]), 0.0)
+    net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, dp)
+    net.load_state_dict(case_params(c), strict=True)
+    net.precision = precision
+    d = mtk.GaussianMultinomialDiffusion(c["K"], c["Nn"], net, num_timesteps=T or c["T"],
+                                         scheduler_type=mtk.SchedulerType(c["sched"]), device=dev())
+    d = d.to(dev())
+    d.precision = precision
+    return d
+
+
+def close(got, want, rtol=RTOL, atol=1e-6):
+    got, want = got.double().cpu(), want.double().cpu()
+    err = (got - want).abs()
+    ok = err <= rtol * want.abs() + atol
+    assert bool(ok.all()), f"max abs err {float(err.max()):.3e}, max rel {float((err / want.abs().clamp_min(1e-9)).max()):.3e}"
+
+
+def check_categorical(got_idx, want_idx, logits, u, K):
+    """Equal, or a Gumbel near-tie in the reference's own arithmetic."""
+    got_idx, want_idx = got_idx.cpu().long(), want_idx.cpu().long()
+    diff = got_idx != want_idx
+    n_bad = int(diff.sum())
+    assert n_bad <= max(1, int(1e-3 * diff.numel())), f"{n_bad} of {diff.numel()} categorical draws differ"
+    if n_bad:
+        off = orc.offsets_of(K)
+        g = -torch.log(-torch.log(u + 1e-30) + 1e-30) + logits
+        for r, k in zip(*np.nonzero(diff.numpy())):
+            blk = g[r, off[k]:off[k + 1]]
+            top2 = torch.topk(blk, 2).values
+            assert float(top2[0] - top2[1]) < TIE_MARGIN, f"row {r} block {k}: differs without a near-tie ({blk.tolist()})"
+
+
+def colmajor(x):
+    """[B, D] host tensor → device [D][B] buffer."""
+    return x.t().contiguous().to(dev())
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_q_sample(tag):
+    c = load_case(tag)
+    d = build(c)
+    eng = d.engine()
+    B, D, C = c["x0"].shape[0], c["D"], c["C"]
+    x0, t = tt(c["x0"]).to(dev()), tt(c["ml_t"]).to(dev())
+    eps = tt(c["ml_eps"]).to(dev()) if c["Nn"] else None
+    u = tt(c["ml_u"]).to(dev()) if C else None
+    for strides, shape in (((1, B), (D, B)), ((D, 1), (B, D))):
+        x_in = torch.full(shape, float("nan"), device=dev())
+        idx = torch.zeros((max(C, 1), B), dtype=torch.int32, device=dev())
+        eng.q_sample(x0, t, eps, u, x_in, strides, idx)
+        x_in_rm = x_in.t() if strides == (1, B) else x_in
+        close(x_in_rm[:, : c["Nn"]], tt(c["ml_x_num_t"]), rtol=1e-6)
+        if C:
+            s = orc.make_schedule(c["T"], c["sched"])
+            logits = orc.q_pred(s, orc.log_onehot(tt(c["x0"])[:, c["Nn"]:].long(), c["K"]), tt(c["ml_t"]), orc.log_k_expanded(c["K"]))
+            check_categorical(idx[:C].t(), tt(c["ml_xt_idx"]), logits, tt(c["ml_u"]), c["K"])
+            same = (idx[:C].t().cpu().long() == tt(c["ml_xt_idx"])).all(dim=1)
+            assert torch.equal(x_in_rm.cpu()[same][:, c["Nn"]:], tt(c["ml_model_in"])[same][:, c["Nn"]:])
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_mlp_forward_fp32(tag):
+    c = load_case(tag)
+    d = build(c)
+    x, t = tt(c["ml_model_in"]).to(dev()), tt(c["ml_t"]).to(dev())
+    with torch.no_grad():
+        out = d._denoise_fn(x, t)
+    want = tt(c["ml_model_out"])
+    scale = float(want.abs().max())
+    close(out, want, rtol=RTOL, atol=1e-5 * scale)
+    # column-major in / out and a scalar timestep
+    B, D = x.shape
+    eng = d.engine()
+    o2 = torch.empty((D, B), device=dev())
+    eng.mlp_forward(x.t().contiguous(), t, out=o2, x_strides=(1, B), out_strides=(1, B), B=B)
+    assert torch.equal(o2.t().contiguous(), out)
+    tv = torch.full((B,), 7, dtype=torch.long)
+    o3 = eng.mlp_forward(x, 7)
+    close(o3, orc.mlp_forward(case_params(c), tt(c["ml_model_in"]), tv), rtol=RTOL, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_loss_rows_with_injected_model_out(tag):
+    c = load_case(tag)
+    d = build(c)
+    eng = d.engine()
+    B, C, Nn = c["x0"].shape[0], c["C"], c["Nn"]
+    x0, t = tt(c["x0"]).to(dev()), tt(c["ml_t"]).to(dev())
+    mo = colmajor(tt(c["ml_model_out"]))
+    idx = tt(c["ml_xt_idx"]).t().contiguous().int().to(dev()) if C else None
+    eps = tt(c["ml_eps"]).to(dev()) if Nn else None
+    lm = torch.empty(B, device=dev()) if C else None
+    lg = torch.empty(B, device=dev()) if Nn else None
+    eng.loss_rows(mo, (1, B), x0, idx, eps, t, lm, lg)
+    if Nn:
+        close(lg, tt(c["ml_lg_rows"]), rtol=1e-5)
+    if C:
+        want = tt(c["ml_lm_rows"])
+        s = orc.make_schedule(c["T"], c["sched"])
+        floor = orc.multinomial_loss_floor(s, c["K"], Nn, tt(c["ml_model_out"]), tt(c["x0"]), tt(c["ml_xt_idx"]), tt(c["ml_t"]))
+        err = (lm.cpu().double() - want.double()).abs()
+        assert bool((err <= RTOL * want.abs().double() + 2 * floor).all()), float((err / (RTOL * want.abs().double() + 2 * floor)).max())
+        assert abs(float(lm.mean().cpu()) - float(want.mean())) <= RTOL * abs(float(want.mean()))
+        # the t == 0 rows take the decoder-NLL branch (rows 0 and 3 of every fixture)
+        assert int(tt(c["ml_t"])[0]) == 0 and bool(torch.isfinite(lm[0].cpu()))
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_mixed_loss_end_to_end(tag):
+    c = load_case(tag)
+    d = build(c)
+    x0 = tt(c["x0"]).to(dev())
+    t = tt(c["ml_t"]).to(dev())
+    eps = tt(c["ml_eps"]).to(dev()) if c["Nn"] else None
+    u = tt(c["ml_u"]).to(dev()) if c["C"] else None
+    lm, lg = d.mixed_loss_rows(x0, timestep=t, noise=eps, uniform=u)
+    if c["Nn"]:
+        close(lg, tt(c["ml_lg_rows"]), rtol=RTOL)
+    else:
+        assert lg.shape == (1,) and float(lg) == 0.0 and not lg.is_cuda
+    if c["C"]:
+        want = tt(c["ml_lm_rows"])
+        assert abs(float(lm.mean().cpu()) - float(want.mean())) <= RTOL * abs(float(want.mean()))
+    else:
+        assert lm.shape == (1,) and float(lm) == 0.0 and not lm.is_cuda
+    # the unmodified entry point, drawing like the reference does
+    torch.manual_seed(3)
+    with torch.no_grad():
+        m, g = d.mixed_loss(x0, {"y": torch.zeros(x0.shape[0], dtype=torch.long, device=dev())})
+    assert m.ndim == 0 and g.ndim == 0 and bool(torch.isfinite(m)) and bool(torch.isfinite(g))
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "N_tf"])
+def test_tf_score_fp32(tag):
+    from midst_toolkit_amd import scoring
+
+    c = load_case(tag)
+    d = build(c)
+    x0 = tt(c["x0"]).to(dev())
+    noise = tt(c["tf_noise"])
+    P = noise.shape[0]
+    for k in range(4):
+        t, add = (int(v) for v in c[f"tf{k}_t"])
+        got = scoring.mixed_loss(d, x0, {"y": None}, noise.tolist(), P, add, t)
+        want = tt(c[f"tf{k}_score"])
+        assert got.shape == want.shape
+        close(got, want, rtol=RTOL)
+        if add == 0:  # membership-score ranking over the records, per noise draw
+            assert torch.equal(torch.argsort(got.cpu(), dim=0, stable=True), torch.argsort(want, dim=0, stable=True))
+    ts = [int(c[f"tf{k}_t"][0]) for k in (0, 1, 3)]
+    many = scoring.score_records(d, x0, noise.to(dev()), ts, 0)
+    for j, k in enumerate((0, 1, 3)):
+        close(many[j], tt(c[f"tf{k}_score"]), rtol=RTOL)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_reverse_steps(tag):
+    c = load_case(tag)
+    d = build(c)
+    eng = d.engine()
+    B, Nn, C, D, S = c["x0"].shape[0], c["Nn"], c["C"], c["D"], c["S"]
+    s = orc.make_schedule(c["T"], c["sched"])
+    for k in range(4):
+        t = int(c[f"rs{k}_t"])
+        mo = colmajor(tt(c[f"rs{k}_model_out"]))
+        z = tt(c[f"rs{k}_z"]).double().t().contiguous().to(dev()) if Nn else None
+        z_idx = tt(c[f"rs{k}_z_idx"]).t().contiguous().int().to(dev()) if C else None
+        n = tt(c[f"rs{k}_n"]).to(dev()) if Nn else None
+        u = tt(c[f"rs{k}_u"]).to(dev()) if C else None
+        x_next = torch.full((D, B), float("nan"), device=dev())
+        eng.p_sample_step(B, t, k == 0, mo, (1, B), z, z_idx, n, u, x_next, (1, B))
+        if Nn:
+            close(z.t(), tt(c[f"rs{k}_z_new"]), rtol=1e-12 if k else 1e-6, atol=1e-12 if k else 1e-7)
+            assert torch.equal(x_next[:Nn].t().cpu(), z.t().float().cpu())
+        if C:
+            check_categorical(z_idx.t(), tt(c[f"rs{k}_z_idx_new"]), tt(c[f"rs{k}_logp"]), tt(c[f"rs{k}_u"]), c["K"])
+            want_oh = orc.log_onehot(z_idx.t().cpu().long(), c["K"])
+            assert torch.equal(x_next[Nn:].t().cpu(), want_oh)
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly"])
+def test_full_chain(tag):
+    c = load_case(tag)
+    Tc = int(c["ch_T"])
+    d = build(c, T=Tc)
+    Nn, C = c["Nn"], c["C"]
+    noise = [tt(n).to(dev()) for n in c["ch_noise"]]
+    if bool(c["ch_first_noise_is_f32"]) and noise:
+        noise[0] = noise[0].float()
+    inj = {"z0": tt(c["ch_z0"]).to(dev()), "noise": noise, "y": torch.zeros(c["ch_z0"].shape[0], dtype=torch.long)}
+    if C:
+        inj["u0"] = tt(c["ch_u0"]).to(dev())
+        inj["u"] = [tt(v).to(dev()) for v in c["ch_u"]]
+    got, outs = d.sample(c["ch_z0"].shape[0], torch.ones(1), _injected=inj)
+    want = tt(c["ch_sample"])
+    assert got.dtype == torch.float64 and got.shape == want.shape and not got.is_cuda
+    same = (got[:, Nn:] == want[:, Nn:]).all(dim=1) if C else torch.ones(got.shape[0], dtype=torch.bool)
+    # a flipped Gumbel near-tie changes that row's whole trajectory; the rest must agree
+    assert float(same.float().mean()) >= 0.97, float(same.float().mean())
+    if Nn:
+        close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=1e-5)
+
+
+def test_sample_all_and_philox_mode():
+    c = load_case("B_ragged")
+    d = build(c, T=12)
+    torch.manual_seed(0)
+    x, y = d.sample_all(50, 32, torch.ones(1))
+    assert x.shape == (50, c["Nn"] + c["C"]) and x.dtype == torch.float64 and y.shape == (50,)
+    cats = x[:, c["Nn"]:]
+    assert bool((cats >= 0).all()) and bool((cats < tt(c["K"]).double()).all()) and bool((cats == cats.round()).all())
+    d.rng = "philox"
+    x2, _ = d.sample_all(40, 40, torch.ones(1))
+    assert x2.shape == (40, c["Nn"] + c["C"]) and bool(torch.isfinite(x2).all())
+    lm, lg = d.mixed_loss_rows(tt(c["x0"]).to(dev()))
+    assert bool(torch.isfinite(lm).all()) and bool(torch.isfinite(lg).all())
+    # in-kernel noise has the right moments: Gaussian loss of an untrained net ~ E[(eps - out)^2]
+    big = torch.randn((8192, c["Nn"])).clamp(-5.2, 5.2)
+    rows = torch.cat([big] + [torch.randint(0, int(k), (8192, 1)).float() for k in c["K"]], 1).to(dev())
+    eng = d.engine()
+    x_in = torch.empty((c["D"], 8192), device=dev())
+    idx = torch.empty((c["C"], 8192), dtype=torch.int32, device=dev())
+    t0 = torch.full((8192,), d.num_timesteps - 1, dtype=torch.long, device=dev())
+    eng.q_sample(rows, t0, None, None, x_in, (1, 8192), idx, seed=99)
+    xn = x_in[: c["Nn"]]
+    assert abs(float(xn.mean())) < 0.05 and abs(float(xn.std()) - 1.0) < 0.05  # x_T ~ N(0, 1)
+    for k, K in enumerate(c["K"]):  # x_T categories ~ uniform
+        freq = torch.bincount(idx[k].long().cpu(), minlength=int(K)).float() / 8192
+        assert float((freq - 1.0 / int(K)).abs().max()) < 0.03
+
+
+def test_bad_arguments_raise():
+    c = load_case("A_numeric")
+    d = build(c)
+    eng = d.engine()
+    x = torch.zeros((4, c["D"]), device=dev())
+    with pytest.raises(AssertionError):
+        eng.mlp_forward(x, 10_000)  # t outside the schedule
+    with pytest.raises(ValueError):
+        d2 = build(load_case("B_ragged"))
+        d2.engine().tf_score(torch.zeros((4, 6), device=dev()), torch.zeros((2, 6), device=dev()), [1])

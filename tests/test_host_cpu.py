@@ -1,0 +1,93 @@
+"""CPU: host-side logic of the product (no compute calls) and the C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import midst_toolkit_amd as mtk
+from midst_toolkit_amd import _lib, schedule
+from oracle import diffusion_oracle as orc
+from tests.helpers import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tag,T,kind", [("cosine_1000", 1000, "cosine"), ("linear_100", 100, "linear")])
+def test_product_schedule_matches_reference_vectors(tag, T, kind):
+    buf = schedule.buffer_values(schedule.SchedulerType(kind), T)
+    post = schedule.posterior_values(buf)
+    with np.load(f"{GOLDEN}/sched_{tag}.npz") as z:
+        for k, v in buf.items():
+            assert np.array_equal(v.float().numpy(), z[k]), k
+        assert np.array_equal(post["posterior_variance"].numpy(), z["posterior_variance_f64"])
+        assert np.array_equal(post["model_log_variance"].numpy(), z["model_log_variance_f64"])
+        for k in ("posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            assert np.array_equal(post[k].numpy(), z[k]), k
+
+
+def test_unsupported_scheduler_raises_value_error():
+    with pytest.raises(ValueError):
+        schedule.get_named_beta_schedule("sigmoid", 10)
+
+
+def test_drop_in_module_surface():
+    dp = mtk.DiffusionParameters([64, 64], 0.0)
+    net = mtk.MLPDiffusion(13, 0, mtk.IsTargetConditioned.NONE, dp)
+    d = mtk.GaussianMultinomialDiffusion(np.array([4, 4, 5]), 0, net, num_timesteps=100,
+                                         scheduler_type=mtk.SchedulerType.LINEAR, device=torch.device("cpu"))
+    names = sorted(dict(d.named_parameters()))
+    want = sorted(f"_denoise_fn.{n}.{w}" for n in orc.mlp_param_names(2) for w in ("weight", "bias"))
+    assert names == want
+    assert len(d.state_dict()) == 26  # 12 parameters + 14 buffers, like the reference
+    assert d.posterior_variance.dtype == torch.float64
+    assert d.offsets.tolist() == [0, 4, 8, 13]
+    # parameters initialised by nn.Linear in the reference's construction order → same values as the oracle's init
+    torch.manual_seed(0)
+    net2 = mtk.MLPDiffusion(13, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+    assert set(dict(net2.named_parameters())) == {f"{n}.{w}" for n in orc.mlp_param_names(2) for w in ("weight", "bias")}
+
+
+def test_no_cpu_path():
+    dp = mtk.DiffusionParameters([16], 0.0)
+    net = mtk.MLPDiffusion(4, 0, mtk.IsTargetConditioned.NONE, dp)
+    d = mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, num_timesteps=10, device=torch.device("cpu"))
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            d.mixed_loss(torch.zeros(3, 4), {"y": torch.zeros(3)})
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            net(torch.zeros(3, 4), torch.zeros(3, dtype=torch.long))
+
+
+def test_unsupported_enums_raise_value_error():
+    dp = mtk.DiffusionParameters([16], 0.0)
+    net = mtk.MLPDiffusion(4, 0, mtk.IsTargetConditioned.NONE, dp)
+    with pytest.raises(ValueError):
+        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_loss_type=mtk.GaussianLossType.KL, device=torch.device("cpu"))
+    with pytest.raises(ValueError):
+        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, parametrization=mtk.Parametrization.DIRECT, device=torch.device("cpu"))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mtk.h")).read()
+    declared = set(re.findall(r"\b(mtk_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mtk_status", "mtk_table", "mtk_precision"}
+    assert declared, "no declarations found"
+    assert os.path.exists(_lib.LIB_PATH), "libmtk_hip.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mtk.h but not exported"
+    assert set(_lib.exported_symbols()) == declared
+    assert lib.mtk_version() >= 100
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "midst-toolkit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"
