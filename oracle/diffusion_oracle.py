@@ -275,8 +275,22 @@ def time_table(params: dict[str, torch.Tensor], T: int, dim_t: int = 128) -> tor
     return F.linear(F.silu(e), params["timestep_embedding.2.weight"], params["timestep_embedding.2.bias"])
 
 
-def mlp_forward(params: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, dim_t: int = 128) -> torch.Tensor:
-    """MODEL:596-615 with ``is_target_conditioned = NONE`` (``y`` ignored), dropout 0."""
+def mlp_forward(params: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, dim_t: int = 128,
+                dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """MODEL:596-615 with ``is_target_conditioned = NONE`` (``y`` ignored), dropout 0.
+    ``dtype=torch.float64`` evaluates the same network in double (used only to measure how far
+    the reference's own fp32 result is from the exact value of its formula)."""
+    if dtype != torch.float32:
+        params = {k: v.to(dtype) for k, v in params.items()}
+        e = timestep_embedding(t, dim_t).to(dtype)
+        e = F.linear(e, params["timestep_embedding.0.weight"], params["timestep_embedding.0.bias"])
+        e = F.linear(F.silu(e), params["timestep_embedding.2.weight"], params["timestep_embedding.2.bias"])
+        h = F.linear(x.to(dtype), params["proj.weight"], params["proj.bias"]) + e
+        i = 0
+        while f"mlp.blocks.{i}.linear.weight" in params:
+            h = F.relu(F.linear(h, params[f"mlp.blocks.{i}.linear.weight"], params[f"mlp.blocks.{i}.linear.bias"]))
+            i += 1
+        return F.linear(h, params["mlp.head.weight"], params["mlp.head.bias"]).float()
     e = timestep_embedding(t, dim_t)
     e = F.linear(e, params["timestep_embedding.0.weight"], params["timestep_embedding.0.bias"])
     e = F.linear(F.silu(e), params["timestep_embedding.2.weight"], params["timestep_embedding.2.bias"])
@@ -351,7 +365,8 @@ def multinomial_p_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tenso
     return gumbel_argmax(logp, u, K)
 
 
-def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us):
+def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us,
+                 mlp_dtype: torch.dtype = torch.float32):
     """a18 / GMD:1370-1424 with injected randomness.  ``noises[i]``/``us[i]`` belong to the i-th
     executed step (t = T-1-i).  Returns [B, Nn+C] fp64 (numeric then category codes)."""
     C = 0 if (len(K) == 0 or int(K[0]) == 0) else len(K)
@@ -362,7 +377,7 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
         z_idx = gumbel_argmax(torch.zeros((B, int(offsets_of(K)[-1]))), u0, K)
     for i, t in enumerate(reversed(range(s.T))):
         tt = torch.full((B,), t, dtype=torch.long)
-        out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt)
+        out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype)
         z = gaussian_p_step(s, out[:, :Nn], z, t, noises[i])
         if C:
             z_idx = multinomial_p_step(s, K, out[:, Nn:], z_idx, t, us[i])

@@ -61,6 +61,16 @@ def check_categorical(got_idx, want_idx, logits, u, K):
             assert float(top2[0] - top2[1]) < TIE_MARGIN, f"row {r} block {k}: differs without a near-tie ({blk.tolist()})"
 
 
+def check_ranking(got, want, tie=4e-6):
+    """Ordering the records by the GPU score orders the reference scores too, except where two
+    reference scores are closer than `tie` relative (fp32 summation-order noise)."""
+    order = torch.argsort(got, dim=0, stable=True)
+    ref_sorted = torch.gather(want, 0, order)
+    drop = ref_sorted[:-1] - ref_sorted[1:]
+    assert bool((drop <= tie * ref_sorted[:-1].abs()).all()), float((drop / ref_sorted[:-1].abs()).max())
+    assert float((order == torch.argsort(want, dim=0, stable=True)).float().mean()) > 0.9
+
+
 def colmajor(x):
     """[B, D] host tensor → device [D][B] buffer."""
     return x.t().contiguous().to(dev())
@@ -177,7 +187,7 @@ def test_tf_score_fp32(tag):
         assert got.shape == want.shape
         close(got, want, rtol=RTOL)
         if add == 0:  # membership-score ranking over the records, per noise draw
-            assert torch.equal(torch.argsort(got.cpu(), dim=0, stable=True), torch.argsort(want, dim=0, stable=True))
+            check_ranking(got.cpu(), want)
     ts = [int(c[f"tf{k}_t"][0]) for k in (0, 1, 3)]
     many = scoring.score_records(d, x0, noise.to(dev()), ts, 0)
     for j, k in enumerate((0, 1, 3)):
@@ -229,7 +239,17 @@ def test_full_chain(tag):
     # a flipped Gumbel near-tie changes that row's whole trajectory; the rest must agree
     assert float(same.float().mean()) >= 0.97, float(same.float().mean())
     if Nn:
-        close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=1e-5)
+        # The chain multiplies eps_hat by sqrt_recipm1_alphas_cumprod (up to 2e4) at every step, so the
+        # reference's own fp32 denoiser rounding already moves the result: measure that (fp32 vs fp64
+        # denoiser inside the oracle) and allow 3x it on top of the 1e-4 relative bar.
+        s = orc.make_schedule(Tc, c["sched"])
+        cpu = lambda v: v.cpu() if isinstance(v, torch.Tensor) else v  # noqa: E731
+        args = (s, c["K"], Nn, case_params(c), cpu(inj["z0"]), cpu(inj.get("u0")), [cpu(n) for n in noise],
+                [cpu(v) for v in inj["u"]] if C else [None] * len(noise))
+        ref64 = orc.sample_chain(*args, mlp_dtype=torch.float64)
+        agree = same & ((ref64[:, Nn:] == want[:, Nn:]).all(dim=1) if C else same)
+        own = float((ref64[agree][:, :Nn] - want[agree][:, :Nn]).abs().max())
+        close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=max(1e-5, 3 * own))
 
 
 def test_sample_all_and_philox_mode():
