@@ -290,3 +290,86 @@ def test_bad_arguments_raise():
     with pytest.raises(ValueError):
         d2 = build(load_case("B_ragged"))
         d2.engine().tf_score(torch.zeros((4, 6), device=dev()), torch.zeros((2, 6), device=dev()), [1])
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 mode (fused register-resident MFMA kernel).  Stated tolerance: operands are rounded to bf16
+# (8 significant bits) at every layer, accumulation is fp32; outputs agree with the fp32 reference to
+# BF16_TOL of the output scale, Tartan-Federer scores to BF16_TOL relative.
+# ------------------------------------------------------------------------------------------------
+BF16_TOL = 2e-2
+
+
+@pytest.mark.parametrize("tag", ["M_mixed", "N_tf"])
+def test_mlp_forward_bf16(tag):
+    c = load_case(tag)
+    d = build(c, precision="bf16")
+    x, t = tt(c["ml_model_in"]).to(dev()), tt(c["ml_t"]).to(dev())
+    with torch.no_grad():
+        out = d._denoise_fn(x, t)
+    want = tt(c["ml_model_out"])
+    scale = float(want.abs().max())
+    err = float((out.cpu() - want).abs().max())
+    assert err <= BF16_TOL * scale, (err, scale)
+    # against the same network evaluated with bf16-rounded operands in fp32 (isolates the kernel's
+    # indexing from the rounding): must be much closer
+    B, D = x.shape
+    eng = d.engine()
+    o2 = torch.empty((D, B), device=dev())
+    eng.mlp_forward(x.t().contiguous(), t, out=o2, precision="bf16", x_strides=(1, B), out_strides=(1, B), B=B)
+    assert torch.equal(o2.t().contiguous(), out)
+    ref = bf16_emulated_forward(case_params(c), tt(c["ml_model_in"]), tt(c["ml_t"]))
+    assert float((out.cpu() - ref).abs().max()) <= 2e-3 * scale, float((out.cpu() - ref).abs().max()) / scale
+    # ragged batch sizes around the 128-row tile
+    for n in (1, 31, 33, 129):
+        o = eng.mlp_forward(x[:n].contiguous(), t[:n].contiguous(), precision="bf16")
+        assert torch.equal(o, out[:n]), n
+
+
+def bf16_emulated_forward(params, x, t):
+    """fp32 math on bf16-rounded weights and activations (what the fused kernel computes, up to
+    summation order)."""
+    import torch.nn.functional as F
+
+    r = lambda v: v.to(torch.bfloat16).float()  # noqa: E731
+    emb = orc.time_table(params, int(t.max()) + 1)[t]
+    h = F.linear(r(x), r(params["proj.weight"]), params["proj.bias"]) + emb
+    i = 0
+    while f"mlp.blocks.{i}.linear.weight" in params:
+        h = F.relu(F.linear(r(h), r(params[f"mlp.blocks.{i}.linear.weight"]), params[f"mlp.blocks.{i}.linear.bias"]))
+        i += 1
+    return F.linear(r(h), r(params["mlp.head.weight"]), params["mlp.head.bias"])
+
+
+def test_tf_score_bf16():
+    from midst_toolkit_amd import scoring
+
+    c = load_case("N_tf")
+    d = build(c, precision="bf16")
+    x0 = tt(c["x0"]).to(dev())
+    noise = tt(c["tf_noise"]).to(dev())
+    ts = [int(c[f"tf{k}_t"][0]) for k in (0, 1, 3)]
+    many = scoring.score_records(d, x0, noise, ts, 0, precision="bf16")
+    for j, k in enumerate((0, 1, 3)):
+        want = tt(c[f"tf{k}_score"])
+        rel = float(((many[j].cpu() - want).abs() / want.abs()).max())
+        assert rel <= BF16_TOL, (k, rel)
+    t2, add2 = (int(v) for v in c["tf2_t"])
+    got = scoring.score_records(d, x0, noise, [t2], add2, precision="bf16")[0]
+    assert float(((got.cpu() - tt(c["tf2_score"])).abs() / tt(c["tf2_score"]).abs()).max()) <= BF16_TOL
+    # a batch that is not a multiple of the tile, many timesteps (> one launch group)
+    ts = list(range(0, 1000, 13))
+    big = scoring.score_records(d, x0[:37], noise, ts, 0, precision="bf16")
+    ref = scoring.score_records(d, x0[:37], noise, ts, 0, precision="fp32")
+    assert big.shape == (len(ts), 37, noise.shape[0])
+    assert float(((big - ref).abs() / ref.abs()).max()) <= BF16_TOL
+
+
+def test_mixed_loss_bf16_mean():
+    c = load_case("M_mixed")
+    d = build(c, precision="bf16")
+    x0, t = tt(c["x0"]).to(dev()), tt(c["ml_t"]).to(dev())
+    lm, lg = d.mixed_loss_rows(x0, timestep=t, noise=tt(c["ml_eps"]).to(dev()), uniform=tt(c["ml_u"]).to(dev()))
+    wm, wg = tt(c["ml_lm_rows"]), tt(c["ml_lg_rows"])
+    assert abs(float(lg.mean().cpu()) - float(wg.mean())) <= BF16_TOL * float(wg.mean())
+    assert abs(float(lm.mean().cpu()) - float(wm.mean())) <= 5 * BF16_TOL * float(wm.mean())
