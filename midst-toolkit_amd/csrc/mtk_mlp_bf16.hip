@@ -17,6 +17,11 @@
 //     wave).  The stream (1.7 MB at 4x512) stays L2-resident; workgroups are persistent over row tiles.
 //   * Time embedding is a [T, 128] table (built when the weights are set) gathered by each record's t and
 //     folded into the initial accumulator together with the bias.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "mtk_common.h"
 
 namespace {
@@ -29,6 +34,7 @@ constexpr int kFragBytes = 1024;
 constexpr int kChunkBytes = kChunkFrags * kFragBytes;
 constexpr int kDimT = 128;
 constexpr int kMaxTF = 64;  // timesteps per fused Tartan-Federer launch
+constexpr int kBufs = 3;     // LDS chunk buffers
 
 struct FusedArgs {
     const unsigned char* wfrag;
@@ -51,6 +57,8 @@ struct FusedArgs {
     float* score;
     const SchedRow* sched;
     int add_t;
+    unsigned long long* stamps;  // diagnostic: per-phase cycle sums (MTK_FUSED_STAMPS=1), else null
+    int exp;  // diagnostic switches (MTK_FUSED_EXP): 1 = no weight DMA after the prologue, 2 = no chunk barrier
     int t_list[kMaxTF];
 };
 
@@ -61,35 +69,92 @@ __device__ __forceinline__ constexpr int feat(int ks, int hh, int j) {
     return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hh + (j & 3);
 }
 
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Weight-fragment pipeline.  Chunk c of the stream lives in LDS buffer c % kBufs.  While chunk c is being
+// consumed, chunk c+1 has landed and chunk c+2 is in flight.
 struct Pipe {
-    const unsigned char* wfrag;
+    const unsigned char* src;  // wfrag + lane * 16
     int total_chunks;
-    int next;      // next chunk of the stream to fetch
-    int buf;       // buffer (0/1) of the chunk being consumed
+    int next;                  // next chunk of the stream to fetch
+    unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer the next fetch goes to
     int lane, wid;
 
-    __device__ __forceinline__ void issue(int into) {
-        const unsigned char* src = wfrag + (size_t)next * kChunkBytes + (size_t)lane * 16;
+    // one LDS-DMA per fragment: 64 lanes x 16 B = 1 KiB, destination = wave-uniform base + lane * 16
+    __device__ __forceinline__ void fetch() {
+        const unsigned char* g = src + (size_t)next * kChunkBytes;
 #pragma unroll
         for (int q = 0; q < kChunkFrags / 4; ++q) {
             const int f = wid + 4 * q;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * kFragBytes),
-                                             (__attribute__((address_space(3))) void*)(mtk_smem_f + into * kChunkBytes + f * kFragBytes),
-                                             16, 0, 0);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(dma + (unsigned)f * kFragBytes);
+            const unsigned char* gp = g + (size_t)f * kFragBytes;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(gp), "s"(dst)
+                : "memory");
         }
         next = (next + 1 == total_chunks) ? 0 : next + 1;
+        dma = (dma + kChunkBytes == kBufs * kChunkBytes) ? 0u : dma + kChunkBytes;
     }
-    // make the next chunk current: its DMA (issued one chunk ago) is drained by the barrier's vmcnt(0);
-    // every wave has finished reading the other buffer, so the chunk after it can be fetched into it
-    __device__ __forceinline__ void advance() {
-        __syncthreads();
-        buf ^= 1;
-        issue(buf ^ 1);
+    // every wave's pieces of the chunk after the current one have landed (vmcnt) and every wave has left
+    // the chunk before the current one (barrier): the buffer of that older chunk is free for the next fetch
+    int exp;
+    __device__ __forceinline__ void sync_and_fetch() {
+        if (!(exp & 2)) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!(exp & 1)) fetch();
     }
-    __device__ __forceinline__ bf16x8 frag(int f) const {
-        return *reinterpret_cast<const bf16x8*>(mtk_smem_f + buf * kChunkBytes + f * kFragBytes + lane * 16);
+    __device__ __forceinline__ void rotate() { rd = (rd + kChunkBytes == kBufs * kChunkBytes) ? 0u : rd + kChunkBytes; }
+    __device__ __forceinline__ bf16x8 ld(int f) const {
+        return *reinterpret_cast<const bf16x8*>(mtk_smem_f + rd + f * kFragBytes + lane * 16);
     }
 };
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+
+// Consume the current chunk (32 fragments) in four quarters.  `step(ic<I>, w)` issues the MFMA of fragment I.
+// Fragment i of the NEXT quarter is read from LDS right before the MFMA of fragment i of the current one,
+// so every ds_read_b128 has eight MFMAs (256 cycles) to return; the issue order is pinned (the scheduler
+// otherwise sinks the reads next to their uses).  On entry w0 holds fragments 0..7 of the chunk; on exit w0
+// holds fragments 0..7 of the next chunk.  The barrier in the middle publishes the chunk after this one.
+template <class Step>
+__device__ __forceinline__ void consume_chunk(Pipe& p, bf16x8 (&w0)[8], bf16x8 (&w1)[8], Step&& step) {
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        w1[i] = p.ld(8 + i);
+        step(std::integral_constant<int, i>{}, w0[i]);
+        PIN();
+    });
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        w0[i] = p.ld(16 + i);
+        step(std::integral_constant<int, 8 + i>{}, w1[i]);
+        PIN();
+    });
+    p.sync_and_fetch();
+    PIN();
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        w1[i] = p.ld(24 + i);
+        step(std::integral_constant<int, 16 + i>{}, w0[i]);
+        PIN();
+    });
+    p.rotate();
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        w0[i] = p.ld(i);
+        step(std::integral_constant<int, 24 + i>{}, w1[i]);
+        PIN();
+    });
+}
 
 __device__ __forceinline__ f32x16 load16(const float* p) {  // p + {0..3, 8..11, 16..19, 24..27}
     f32x16 v;
@@ -101,61 +166,153 @@ __device__ __forceinline__ f32x16 load16(const float* p) {  // p + {0..3, 8..11,
     return v;
 }
 
+// max(x, 0) as one integer max on the bit pattern (negative floats are negative integers)
+__device__ __forceinline__ float relu_bits(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
+// bias/ReLU epilogue of one 32-feature tile: the fp32 accumulator becomes two bf16 k-steps of the next layer
+template <bool RELU>
 __device__ __forceinline__ void pack_out(const f32x16& v, bf16x8& lo, bf16x8& hi) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lo[j] = (__bf16)v[j];
-        hi[j] = (__bf16)v[8 + j];
+        lo[j] = (__bf16)(RELU ? relu_bits(v[j]) : v[j]);
+        hi[j] = (__bf16)(RELU ? relu_bits(v[8 + j]) : v[8 + j]);
     }
 }
 
-// One dense layer: NT output tiles of 32 features, KS k-steps of 16 inputs.  NPC tiles share a chunk.
-template <int KS, int NT, bool RELU, int NIN, int NOUT>
-__device__ __forceinline__ void dense(const bf16x8 (&Xin)[NIN], bf16x8 (&Xout)[NOUT], Pipe& p, const float* sbias, int hh) {
-    constexpr int NPC = kChunkFrags / KS;
-    static_assert(NPC >= 1 && NT % NPC == 0, "layer must fill whole chunks");
-#pragma unroll
-    for (int c = 0; c < NT / NPC; ++c) {
-        p.advance();
-#pragma unroll
-        for (int q = 0; q < NPC; ++q) {
-            const int nt = c * NPC + q;
-            f32x16 acc = load16(sbias + 32 * nt + 4 * hh);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.frag(q * KS + ks), Xin[ks], acc, 0, 0, 0);
-            if (RELU) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+// One dense layer, k-step-major: fragment g of the layer multiplies k-step g / NT into accumulator g % NT, so
+// all NT accumulators (AGPRs) advance together and one activation fragment feeds NT MFMAs.  In the LAST k-step
+// each MFMA writes a fresh register tile whose epilogue (ReLU, cvt to bf16, in-place store into the activation
+// array) is issued one MFMA later, and the accumulator is reloaded with the next layer's bias.
+template <int KS, int NT, int CHUNKS, bool RELU, int NT_NEXT, int NIN, int NOUT, int NACC>
+__device__ __forceinline__ void dense(Pipe& p, bf16x8 (&w0)[8], bf16x8 (&w1)[8], const bf16x8 (&Xin)[NIN], bf16x8 (&Xout)[NOUT],
+                                      f32x16 (&acc)[NACC], const float* next_bias, int hh) {
+    f32x16 o[2];
+    static_for<CHUNKS>([&](auto cc) {
+        consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) {
+            constexpr int g = decltype(cc)::value * kChunkFrags + decltype(ic)::value, ks = g / NT, nt = g % NT;
+            if constexpr (ks < KS - 1) {
+                acc[nt] = MFMA(w, Xin[ks], acc[nt]);
+            } else if constexpr (ks == KS - 1) {
+                if (p.exp & 4) { acc[nt] = MFMA(w, Xin[ks], acc[nt]); return; }
+                o[nt & 1] = MFMA(w, Xin[ks], acc[nt]);
+                if constexpr (nt < NT_NEXT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
+                if constexpr (nt >= 1) pack_out<RELU>(o[(nt - 1) & 1], Xout[2 * (nt - 1)], Xout[2 * (nt - 1) + 1]);
+                if constexpr (nt == NT - 1) pack_out<RELU>(o[nt & 1], Xout[2 * nt], Xout[2 * nt + 1]);
             }
-            pack_out(acc, Xout[2 * nt], Xout[2 * nt + 1]);
-        }
-    }
+        });
+    });
+    static_for<NT_NEXT>([&](auto ic) {
+        constexpr int nt = decltype(ic)::value;
+        if constexpr (nt >= NT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
+    });
 }
 
-// Output layer: DT tiles of 32 features out of H inputs; the result is stored (mode 0) or reduced (mode 1).
-template <int KS, int DT, int NIN>
-__device__ __forceinline__ void head(const bf16x8 (&Xin)[NIN], Pipe& p, const float* sbias, int hh, const FusedArgs& a, int64_t row,
-                                     bool valid) {
-    constexpr int NPC = (kChunkFrags / KS) < 1 ? 1 : (kChunkFrags / KS);
-    constexpr int NCH = (DT + NPC - 1) / NPC;
-    float sq = 0.0f;
-    const int p_idx = (a.mode == 1) ? (int)(row % a.P) : 0;
+template <int H, int DT, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
+    constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
+    constexpr int KSH = H / 16;   // k-steps of a hidden activation
+    constexpr int NTH = H / 32;   // tiles of a hidden layer
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* sbias = reinterpret_cast<float*>(mtk_smem_f + kBufs * kChunkBytes);
+    for (int i = tid; i < a.n_bias + H; i += 256) sbias[i] = i < a.n_bias ? a.bias[i] : 0.0f;
+
+    Pipe p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, a.exp};
+    p.fetch();  // chunk 0 -> buffer 0
+    p.fetch();  // chunk 1 -> buffer 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk 0 (and the biases) visible to every wave; the next fetch goes to buffer 2
+    bf16x8 w0[8], w1[8];
+    static_for<8>([&](auto ic) { w0[decltype(ic)::value] = p.ld(decltype(ic)::value); });
+
+    f32x16 acc[NTH];
+    bf16x8 X[KSH];
+    unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            PIN();
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            PIN();
+            if (slot >= 0) st_sum[slot] += tnow - st_prev;
+            st_prev = tnow;
+        }
+    };
+    const int64_t n_tiles = (a.rows + 127) / 128;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t row = tile * 128 + wid * 32 + li;
+        const bool valid = row < a.rows;
+        bf16x8 XI[KS0];
+        int t_row = 0, p_idx = 0;
+        stamp(-1);
+        // ---- input fragments
+        if (a.mode == 0) {
+            t_row = a.tvec ? (valid ? (int)a.tvec[row] : 0) : a.t_scalar;
+            static_for<KS0>([&](auto ic) {
+                constexpr int ks = decltype(ic)::value;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        p.advance();
+                for (int j = 0; j < 8; ++j) {
+                    const int f = feat(ks, hh, j);
+                    const float v = (valid && f < a.D) ? a.x[row * a.x_rs + (int64_t)f * a.x_cs] : 0.0f;
+                    XI[ks][j] = (__bf16)v;
+                }
+            });
+        } else {
+            const int64_t k = valid ? row / a.BP : 0;
+            const int64_t rr = row - k * a.BP;
+            const int64_t rec = rr / a.P;
+            p_idx = (int)(rr - rec * a.P);
+            t_row = a.t_list[k];
+            const SchedRow sr = a.sched[t_row + a.add_t];
+            static_for<KS0>([&](auto ic) {
+                constexpr int ks = decltype(ic)::value;
 #pragma unroll
-        for (int q = 0; q < NPC; ++q) {
-            const int nt = c * NPC + q;
-            if (nt >= DT) continue;
-            f32x16 acc = load16(sbias + 32 * nt + 4 * hh);
+                for (int j = 0; j < 8; ++j) {
+                    const int f = feat(ks, hh, j);
+                    const float v = (valid && f < a.D) ? sr.sqrt_acp * a.x[rec * a.x_ld + f] + sr.sqrt_1m_acp * a.noise[p_idx * a.D + f] : 0.0f;
+                    XI[ks][j] = (__bf16)v;
+                }
+            });
+        }
+        // ---- proj (D -> 128): accumulators start at bias + emb[t]   (MODEL:614)
+        const float* er = a.emb + (int64_t)t_row * a.emb_ld;
+        static_for<kDimT / 32>([&](auto ic) {
+            constexpr int nt = decltype(ic)::value;
+            acc[nt] = load16(sbias + 32 * nt + 4 * hh);
+            const f32x16 e = load16(er + 32 * nt + 4 * hh);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.frag(q * KS + ks), Xin[ks], acc, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) acc[nt][r] += e[r];
+        });
+        const float* sb = sbias + kDimT;
+        stamp(0);  // prologue (input loads, emb gather)
+        bf16x8 XP[kDimT / 16];  // proj output; not in X: the 128 -> H layer reads its last k-step while X is rewritten
+        dense<KS0, kDimT / 32, 1, false, NTH>(p, w0, w1, XI, XP, acc, sb, hh);
+        // ---- hidden layers (MODEL:300-301); activations are rewritten in place
+        sb += H;
+        stamp(1);  // proj
+        dense<kDimT / 16, NTH, NTH*(kDimT / 16) / kChunkFrags, true, NTH>(p, w0, w1, XP, X, acc, sb, hh);
+        stamp(2);  // 128 -> H
+        for (int l = 1; l < a.n_hidden; ++l) {
+            sb += H;
+            dense<KSH, NTH, NTH * KSH / kChunkFrags, true, NTH>(p, w0, w1, X, X, acc, sb, hh);
+        }
+        stamp(3);  // H -> H layers
+        // (after the last hidden layer acc[0] holds the head's bias for output tile 0: the bias image continues)
+        // ---- head (H -> D): one chunk (32 k-steps, one accumulator) per output tile   (MODEL:303)
+        float sq = 0.0f;
+        static_for<DT>([&](auto tc) {
+            constexpr int nt = decltype(tc)::value;
+            if constexpr (nt > 0) acc[0] = load16(sb + 32 * nt + 4 * hh);
+            consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) { acc[0] = MFMA(w, X[decltype(ic)::value], acc[0]); });
             if (a.mode == 0) {
                 if (valid) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
-                        if (f < a.D) a.out[row * a.o_rs + (int64_t)f * a.o_cs] = acc[r];
+                        if (f < a.D) a.out[row * a.o_rs + (int64_t)f * a.o_cs] = acc[0][r];
                     }
                 }
             } else {
@@ -163,109 +320,33 @@ __device__ __forceinline__ void head(const bf16x8 (&Xin)[NIN], Pipe& p, const fl
                 for (int r = 0; r < 16; ++r) {
                     const int f = 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
                     if (f < a.D) {
-                        const float d = a.noise[p_idx * a.D + f] - acc[r];
+                        const float d = a.noise[p_idx * a.D + f] - acc[0][r];
                         sq += d * d;
                     }
                 }
             }
+        });
+        if (a.mode == 1) {  // TF:92-95: mean over the numeric features
+            sq += __shfl_xor(sq, 32);
+            if (valid && hh == 0) a.score[row] = sq / (float)a.D;
         }
+        stamp(4);  // head + output
+        if constexpr (STAMP) st_sum[5] += 1;
     }
-    if (a.mode == 1) {
-        sq += __shfl_xor(sq, 32);
-        if (valid && hh == 0) a.score[row] = sq / (float)a.D;
+    if constexpr (STAMP) {
+        if (lane == 0 && wid == 0)
+            for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_sum[i]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches must land before the LDS is released
 }
 
-template <int H, int DT>
-__global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
-    constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
-    constexpr int KSH = H / 16;   // k-steps of a hidden activation
-    constexpr int NTH = H / 32;   // tiles of a hidden layer
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* sbias = reinterpret_cast<float*>(mtk_smem_f + 2 * kChunkBytes);
-    for (int i = tid; i < a.n_bias; i += 256) sbias[i] = a.bias[i];
-
-    Pipe p{a.wfrag, a.total_chunks, 0, 1, lane, wid};
-    p.issue(0);  // chunk 0 -> buffer 0; the first advance() flips buf to 0
-
-    const int64_t n_tiles = (a.rows + 127) / 128;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t row = tile * 128 + wid * 32 + li;
-        const bool valid = row < a.rows;
-        bf16x8 XA[KSH], XB[KSH];
-        int t_row = 0;
-        // ---- input fragments
-        if (a.mode == 0) {
-            t_row = a.tvec ? (valid ? (int)a.tvec[row] : 0) : a.t_scalar;
-#pragma unroll
-            for (int ks = 0; ks < KS0; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = feat(ks, hh, j);
-                    const float v = (valid && f < a.D) ? a.x[row * a.x_rs + (int64_t)f * a.x_cs] : 0.0f;
-                    XA[ks][j] = (__bf16)v;
-                }
-        } else {
-            const int64_t k = valid ? row / a.BP : 0;
-            const int64_t rr = row - k * a.BP;
-            const int64_t rec = rr / a.P;
-            const int pp = (int)(rr - rec * a.P);
-            t_row = a.t_list[k];
-            const SchedRow sr = a.sched[t_row + a.add_t];
-#pragma unroll
-            for (int ks = 0; ks < KS0; ++ks)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = feat(ks, hh, j);
-                    const float v = (valid && f < a.D) ? sr.sqrt_acp * a.x[rec * a.x_ld + f] + sr.sqrt_1m_acp * a.noise[pp * a.D + f] : 0.0f;
-                    XA[ks][j] = (__bf16)v;
-                }
-        }
-        // ---- proj (D -> 128) + bias + emb[t]   (MODEL:614)
-        {
-            p.advance();
-            const float* er = a.emb + (int64_t)t_row * a.emb_ld;
-#pragma unroll
-            for (int nt = 0; nt < kDimT / 32; ++nt) {
-                f32x16 acc = load16(sbias + 32 * nt + 4 * hh);
-                const f32x16 e = load16(er + 32 * nt + 4 * hh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] += e[r];
-#pragma unroll
-                for (int ks = 0; ks < KS0; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p.frag(nt * KS0 + ks), XA[ks], acc, 0, 0, 0);
-                pack_out(acc, XB[2 * nt], XB[2 * nt + 1]);
-            }
-        }
-        // ---- hidden layers (MODEL:300-301), activations alternate between the two register arrays
-        const float* sb = sbias + kDimT;
-        dense<kDimT / 16, NTH, true>(XB, XA, p, sb, hh);
-        sb += H;
-        int rem = a.n_hidden - 1;
-        while (rem >= 2) {
-            dense<KSH, NTH, true>(XA, XB, p, sb, hh);
-            sb += H;
-            dense<KSH, NTH, true>(XB, XA, p, sb, hh);
-            sb += H;
-            rem -= 2;
-        }
-        if (rem == 1) {
-            dense<KSH, NTH, true>(XA, XB, p, sb, hh);
-            sb += H;
-            head<KSH, DT>(XB, p, sb, hh, a, row, valid);
-        } else {
-            head<KSH, DT>(XA, p, sb, hh, a, row, valid);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetch must land before the LDS is released
-}
-
-__global__ void k_pack_frags(unsigned short* dst, const float* W, int out, int in, int NT, int KS, int64_t frag0) {
+// order 0: k-step-major (fragment = ks * NT + nt), order 1: tile-major (fragment = nt * KS + ks)
+__global__ void k_pack_frags(unsigned short* dst, const float* W, int out, int in, int NT, int KS, int order, int64_t frag0) {
     const int64_t n = (int64_t)NT * KS * 512;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t frag = e >> 9;
         const int lane = (int)((e >> 3) & 63), j = (int)(e & 7);
-        const int nt = (int)(frag / KS), ks = (int)(frag % KS);
+        const int nt = order ? (int)(frag / KS) : (int)(frag % NT), ks = order ? (int)(frag % KS) : (int)(frag / NT);
         const int nrow = 32 * nt + (lane & 31);
         const int f = feat(ks, lane >> 5, j);
         const float v = (nrow < out && f < in) ? W[(int64_t)nrow * in + f] : 0.0f;
@@ -330,10 +411,31 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     a.n_hidden = L.n_hidden;
     a.total_chunks = L.total_chunks;
     a.D = c->D;
+    static const int exp_env = getenv("MTK_FUSED_EXP") ? atoi(getenv("MTK_FUSED_EXP")) : 0;
+    a.exp = exp_env;
     const int64_t tiles = (a.rows + 127) / 128;
     const int cus = n_cus(c->device);
     const int grid = (int)(tiles < cus ? tiles : cus);
-    const size_t lds = 2 * kChunkBytes + (((size_t)L.n_bias * 4 + 15) & ~(size_t)15);
+    static const bool stamps_env = getenv("MTK_FUSED_STAMPS") != nullptr;
+    if (stamps_env && L.DT == 1) {
+        static unsigned long long* d_st = nullptr;
+        if (!d_st) {
+            MTK_HIP(hipMalloc(&d_st, 64));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBufs * kChunkBytes + 32 * 1024);
+        }
+        MTK_HIP(hipMemsetAsync(d_st, 0, 64, s));
+        a.stamps = d_st;
+        const size_t lds2 = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H) * 4 + 15) & ~(size_t)15);
+        hipLaunchKernelGGL((k_fused<512, 1, true>), dim3(grid), dim3(256), lds2, s, a);
+        MTK_HIP(hipStreamSynchronize(s));
+        unsigned long long h[8];
+        MTK_HIP(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
+        const double n = (double)h[5] > 0 ? (double)h[5] : 1.0;
+        fprintf(stderr, "[mtk stamps] tiles/wg-sum=%llu cycles/tile: prologue %.0f proj %.0f l1 %.0f hh %.0f head %.0f\n", h[5], h[0] / n, h[1] / n,
+                h[2] / n, h[3] / n, h[4] / n);
+        return MTK_OK;
+    }
+    const size_t lds = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H) * 4 + 15) & ~(size_t)15);
     return launch<512>(L, a, grid, lds, s);
 }
 
@@ -357,7 +459,7 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
     if (!layout_for(c, L)) return MTK_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        const int max_lds = 2 * kChunkBytes + 64 * 1024;
+        const int max_lds = kBufs * kChunkBytes + 32 * 1024;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -373,21 +475,21 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
     const int H = L.H, ksh = H / 16, nth = H / 32;
     int64_t chunk = 0;
     int boff = 0;
-    auto pack = [&](const MlpLayer& l, int NT, int KS, int chunks) {
-        hipLaunchKernelGGL(k_pack_frags, dim3(512), dim3(256), 0, s, dst, l.w32, l.out_pad, l.in_pad, NT, KS, chunk * kChunkFrags);
+    auto pack = [&](const MlpLayer& l, int NT, int KS, int order, int chunks) {
+        hipLaunchKernelGGL(k_pack_frags, dim3(512), dim3(256), 0, s, dst, l.w32, l.out_pad, l.in_pad, NT, KS, order, chunk * kChunkFrags);
         (void)hipMemcpyAsync(c->d_bias_all + boff, l.b32, sizeof(float) * (l.out < 32 * NT ? l.out : 32 * NT), hipMemcpyDeviceToDevice, s);
         chunk += chunks;
     };
     // note: w32 is the zero-padded [out_pad][in_pad] image, so out_pad/in_pad are its true extents
-    pack(c->proj, kDimT / 32, 2 * L.DT, 1);
+    pack(c->proj, kDimT / 32, 2 * L.DT, 0, 1);
     boff += kDimT;
-    pack(c->blocks[0], nth, kDimT / 16, nth * (kDimT / 16) / kChunkFrags);
+    pack(c->blocks[0], nth, kDimT / 16, 0, nth * (kDimT / 16) / kChunkFrags);
     boff += H;
     for (int i = 1; i < c->n_hidden; ++i) {
-        pack(c->blocks[i], nth, ksh, nth * ksh / kChunkFrags);
+        pack(c->blocks[i], nth, ksh, 0, nth * ksh / kChunkFrags);
         boff += H;
     }
-    pack(c->head, L.DT, ksh, (L.DT * ksh + kChunkFrags - 1) / kChunkFrags);
+    pack(c->head, L.DT, ksh, 1, (L.DT * ksh + kChunkFrags - 1) / kChunkFrags);
     MTK_HIP(hipGetLastError());
     MTK_HIP(hipStreamSynchronize(s));
     c->fused_ok = true;
