@@ -68,6 +68,7 @@ struct mtk_ctx {
     void* d_wfrag = nullptr;   // packed MFMA A-fragments, consumption order
     size_t wfrag_bytes = 0;
     float* d_bias_all = nullptr;  // concatenated padded biases for the fused kernel
+    float* d_embb = nullptr;      // [T][emb_ld] time-embedding table + proj bias (fused kernel)
     bool fused_ok = false;
     int fused_h = 0;
     // workspace for the layered fp32 path

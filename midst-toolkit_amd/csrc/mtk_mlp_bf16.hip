@@ -34,14 +34,16 @@ constexpr int kFragBytes = 1024;
 constexpr int kChunkBytes = kChunkFrags * kFragBytes;
 constexpr int kDimT = 128;
 constexpr int kMaxTF = 64;  // timesteps per fused Tartan-Federer launch
-constexpr int kBufs = 3;     // LDS chunk buffers
+constexpr int kBufs = 4;     // LDS chunk buffers
+constexpr int kMaxNoise = 2048;  // floats of the [P, Nn] noise table staged in LDS
 
 struct FusedArgs {
     const unsigned char* wfrag;
     const float* bias;
     int n_bias;
-    const float* emb;
+    const float* embb;  // [T][emb_ld] time-embedding table with the proj bias folded in
     int emb_ld;
+    int n_noise;        // floats of the Tartan-Federer noise table staged in LDS (P * D)
     int n_hidden;
     int total_chunks;
     int64_t rows;
@@ -77,23 +79,25 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-// Weight-fragment pipeline.  Chunk c of the stream lives in LDS buffer c % kBufs.  While chunk c is being
-// consumed, chunk c+1 has landed and chunk c+2 is in flight.
+// Weight-fragment pipeline.  Chunk c of the stream lives in LDS buffer c % kBufs (kBufs = 4).  While chunk c is
+// consumed, chunk c+1 has landed, chunk c+2 is in flight and chunk c+3 is being requested, one 1-KiB piece per
+// wave every fourth MFMA (an LDS-DMA costs the issuing wave tens of cycles, so the pieces are spread out rather
+// than issued as a burst that would drain the matrix pipe).
 struct Pipe {
     const unsigned char* src;  // wfrag + lane * 16
     int total_chunks;
-    int next;                  // next chunk of the stream to fetch
-    unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer the next fetch goes to
+    int next;                  // chunk of the stream being requested
+    unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer being filled
     int lane, wid;
+    int exp;
 
-    // one LDS-DMA per fragment: 64 lanes x 16 B = 1 KiB, destination = wave-uniform base + lane * 16
-    __device__ __forceinline__ void fetch() {
-        const unsigned char* g = src + (size_t)next * kChunkBytes;
-#pragma unroll
-        for (int q = 0; q < kChunkFrags / 4; ++q) {
-            const int f = wid + 4 * q;
+    // piece K (0..7) of the chunk being requested: fragment wid + 4 K; 64 lanes x 16 B, dest = base + lane * 16
+    template <int K>
+    __device__ __forceinline__ void piece() {
+        if (!(exp & 1)) {
+            const int f = wid + 4 * K;
             const unsigned dst = __builtin_amdgcn_readfirstlane(dma + (unsigned)f * kFragBytes);
-            const unsigned char* gp = g + (size_t)f * kFragBytes;
+            const unsigned char* gp = src + (size_t)next * kChunkBytes + (size_t)f * kFragBytes;
             unsigned keep;
             asm volatile(
                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -101,15 +105,19 @@ struct Pipe {
                 : "v"(gp), "s"(dst)
                 : "memory");
         }
-        next = (next + 1 == total_chunks) ? 0 : next + 1;
-        dma = (dma + kChunkBytes == kBufs * kChunkBytes) ? 0u : dma + kChunkBytes;
+        if constexpr (K == 7) {
+            next = (next + 1 == total_chunks) ? 0 : next + 1;
+            dma = (dma + kChunkBytes == kBufs * kChunkBytes) ? 0u : dma + kChunkBytes;
+        }
     }
-    // every wave's pieces of the chunk after the current one have landed (vmcnt) and every wave has left
-    // the chunk before the current one (barrier): the buffer of that older chunk is free for the next fetch
-    int exp;
-    __device__ __forceinline__ void sync_and_fetch() {
-        if (!(exp & 2)) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (!(exp & 1)) fetch();
+    __device__ __forceinline__ void fetch_all() {
+        static_for<8>([&](auto ic) { piece<decltype(ic)::value>(); });
+    }
+    // Placed before the last quarter of chunk m.  vmcnt(8): all of this wave's pieces except the 8 youngest
+    // (chunk m+2) have landed, so chunk m+1 is complete; the barrier extends that to every wave and also says
+    // every wave is done with chunk m-1, whose buffer the following pieces (chunk m+3) overwrite.
+    __device__ __forceinline__ void sync() {
+        if (!(exp & 2)) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     }
     __device__ __forceinline__ void rotate() { rd = (rd + kChunkBytes == kBufs * kChunkBytes) ? 0u : rd + kChunkBytes; }
     __device__ __forceinline__ bf16x8 ld(int f) const {
@@ -121,39 +129,30 @@ struct Pipe {
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
 // Consume the current chunk (32 fragments) in four quarters.  `step(ic<I>, w)` issues the MFMA of fragment I.
-// Fragment i of the NEXT quarter is read from LDS right before the MFMA of fragment i of the current one,
-// so every ds_read_b128 has eight MFMAs (256 cycles) to return; the issue order is pinned (the scheduler
-// otherwise sinks the reads next to their uses).  On entry w0 holds fragments 0..7 of the chunk; on exit w0
-// holds fragments 0..7 of the next chunk.  The barrier in the middle publishes the chunk after this one.
+// Fragment i of the NEXT quarter is read from LDS right before the MFMA of fragment i of the current one, so
+// every ds_read_b128 has eight MFMAs (256 cycles) to return; the issue order is pinned (the scheduler otherwise
+// sinks the reads next to their uses).  On entry w0 holds fragments 0..7 of the chunk; on exit w0 holds
+// fragments 0..7 of the next chunk.
+template <int Q, class Step>
+__device__ __forceinline__ void quarter(Pipe& p, bf16x8 (&cur)[8], bf16x8 (&nxt)[8], Step&& step) {
+    static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        nxt[i] = p.ld(((Q + 1) & 3) * 8 + i);
+        step(std::integral_constant<int, Q * 8 + i>{}, cur[i]);
+        if constexpr (i == 1) p.template piece<(2 * Q + 2) & 7>();
+        if constexpr (i == 5) p.template piece<(2 * Q + 3) & 7>();
+        PIN();
+    });
+}
 template <class Step>
 __device__ __forceinline__ void consume_chunk(Pipe& p, bf16x8 (&w0)[8], bf16x8 (&w1)[8], Step&& step) {
-    static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        w1[i] = p.ld(8 + i);
-        step(std::integral_constant<int, i>{}, w0[i]);
-        PIN();
-    });
-    static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        w0[i] = p.ld(16 + i);
-        step(std::integral_constant<int, 8 + i>{}, w1[i]);
-        PIN();
-    });
-    p.sync_and_fetch();
+    quarter<0>(p, w0, w1, step);  // pieces 2, 3
+    quarter<1>(p, w1, w0, step);  // pieces 4, 5
+    quarter<2>(p, w0, w1, step);  // pieces 6, 7 -> the request moves on to the next chunk
+    p.sync();
     PIN();
-    static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        w1[i] = p.ld(24 + i);
-        step(std::integral_constant<int, 16 + i>{}, w0[i]);
-        PIN();
-    });
-    p.rotate();
-    static_for<8>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        w0[i] = p.ld(i);
-        step(std::integral_constant<int, 24 + i>{}, w1[i]);
-        PIN();
-    });
+    p.rotate();                   // the last quarter prefetches fragments 0..7 of the next chunk
+    quarter<3>(p, w1, w0, step);  // pieces 0, 1 of the new request
 }
 
 __device__ __forceinline__ f32x16 load16(const float* p) {  // p + {0..3, 8..11, 16..19, 24..27}
@@ -189,21 +188,26 @@ __device__ __forceinline__ void pack_out(const f32x16& v, bf16x8& lo, bf16x8& hi
 template <int KS, int NT, int CHUNKS, bool RELU, int NT_NEXT, int NIN, int NOUT, int NACC>
 __device__ __forceinline__ void dense(Pipe& p, bf16x8 (&w0)[8], bf16x8 (&w1)[8], const bf16x8 (&Xin)[NIN], bf16x8 (&Xout)[NOUT],
                                       f32x16 (&acc)[NACC], const float* next_bias, int hh) {
-    f32x16 o[2];
+    // epilogue of one finished tile: ReLU, cvt to bf16 into the activation array, accumulator <- next bias
+    auto finish = [&](auto tc) {
+        constexpr int nt = decltype(tc)::value;
+        pack_out<RELU>(acc[nt], Xout[2 * nt], Xout[2 * nt + 1]);
+        if constexpr (nt < NT_NEXT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
+    };
     static_for<CHUNKS>([&](auto cc) {
         consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) {
             constexpr int g = decltype(cc)::value * kChunkFrags + decltype(ic)::value, ks = g / NT, nt = g % NT;
-            if constexpr (ks < KS - 1) {
-                acc[nt] = MFMA(w, Xin[ks], acc[nt]);
-            } else if constexpr (ks == KS - 1) {
-                if (p.exp & 4) { acc[nt] = MFMA(w, Xin[ks], acc[nt]); return; }
-                o[nt & 1] = MFMA(w, Xin[ks], acc[nt]);
-                if constexpr (nt < NT_NEXT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
-                if constexpr (nt >= 1) pack_out<RELU>(o[(nt - 1) & 1], Xout[2 * (nt - 1)], Xout[2 * (nt - 1) + 1]);
-                if constexpr (nt == NT - 1) pack_out<RELU>(o[nt & 1], Xout[2 * nt], Xout[2 * nt + 1]);
+            if constexpr (ks < KS) acc[nt] = MFMA(w, Xin[ks], acc[nt]);
+            if constexpr (ks == KS - 1) {  // last k-step: finish the tile issued two MFMAs ago
+                if (p.exp & 4) return;
+                if constexpr (nt >= 2) finish(std::integral_constant<int, nt - 2>{});
             }
         });
     });
+    if (!(p.exp & 4)) {
+        if constexpr (NT >= 2) finish(std::integral_constant<int, NT - 2>{});
+        finish(std::integral_constant<int, NT - 1>{});
+    }
     static_for<NT_NEXT>([&](auto ic) {
         constexpr int nt = decltype(ic)::value;
         if constexpr (nt >= NT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
@@ -215,16 +219,34 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
     constexpr int KSH = H / 16;   // k-steps of a hidden activation
     constexpr int NTH = H / 32;   // tiles of a hidden layer
+    constexpr int HA = NTH - 4;   // first of the four accumulators the head uses (split-K)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // LDS after the chunk buffers: biases (+H zeros), the Tartan-Federer noise table, per-timestep (a, b)
     float* sbias = reinterpret_cast<float*>(mtk_smem_f + kBufs * kChunkBytes);
+    float* snoise = sbias + a.n_bias + H;
+    float2* scoef = reinterpret_cast<float2*>(snoise + a.n_noise);
     for (int i = tid; i < a.n_bias + H; i += 256) sbias[i] = i < a.n_bias ? a.bias[i] : 0.0f;
+    if (a.mode == 1) {
+        for (int i = tid; i < a.n_noise; i += 256) snoise[i] = a.noise[i];
+        for (int i = tid; i < kMaxTF; i += 256) {
+            const SchedRow sr = a.sched[a.t_list[i] + a.add_t];
+            scoef[i] = make_float2(sr.sqrt_acp, sr.sqrt_1m_acp);
+        }
+    }
 
     Pipe p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, a.exp};
-    p.fetch();  // chunk 0 -> buffer 0
-    p.fetch();  // chunk 1 -> buffer 1
+    {
+        const int keep_exp = p.exp;
+        p.exp &= ~1;
+        p.fetch_all();  // chunk 0 -> buffer 0
+        p.fetch_all();  // chunk 1 -> buffer 1
+        p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
+        p.template piece<1>();
+        p.exp = keep_exp;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // chunk 0 (and the biases) visible to every wave; the next fetch goes to buffer 2
+    __syncthreads();  // chunks 0, 1 and the LDS tables visible to every wave
     bf16x8 w0[8], w1[8];
     static_for<8>([&](auto ic) { w0[decltype(ic)::value] = p.ld(decltype(ic)::value); });
 
@@ -241,53 +263,75 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             st_prev = tnow;
         }
     };
+
+    // ---- per-tile inputs are requested one tile ahead (a single wave per SIMD has nothing else to hide a
+    // ---- global-memory round trip behind): the timestep first, then the record and the emb[t] + bias rows
     const int64_t n_tiles = (a.rows + 127) / 128;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t row = tile * 128 + wid * 32 + li;
-        const bool valid = row < a.rows;
-        bf16x8 XI[KS0];
-        int t_row = 0, p_idx = 0;
-        stamp(-1);
-        // ---- input fragments
+    struct Where { int64_t row; bool valid; int64_t xoff; int kk, pp; };
+    auto locate = [&](int64_t tile) {
+        Where w;
+        w.row = tile * 128 + wid * 32 + li;
+        w.valid = tile < n_tiles && w.row < a.rows;
+        w.kk = 0; w.pp = 0;
         if (a.mode == 0) {
-            t_row = a.tvec ? (valid ? (int)a.tvec[row] : 0) : a.t_scalar;
-            static_for<KS0>([&](auto ic) {
-                constexpr int ks = decltype(ic)::value;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = feat(ks, hh, j);
-                    const float v = (valid && f < a.D) ? a.x[row * a.x_rs + (int64_t)f * a.x_cs] : 0.0f;
-                    XI[ks][j] = (__bf16)v;
-                }
-            });
+            w.xoff = w.row * a.x_rs;
         } else {
-            const int64_t k = valid ? row / a.BP : 0;
-            const int64_t rr = row - k * a.BP;
+            const int64_t k = w.valid ? w.row / a.BP : 0;
+            const int64_t rr = w.row - k * a.BP;
             const int64_t rec = rr / a.P;
-            p_idx = (int)(rr - rec * a.P);
-            t_row = a.t_list[k];
-            const SchedRow sr = a.sched[t_row + a.add_t];
+            w.kk = (int)k;
+            w.pp = (int)(rr - rec * a.P);
+            w.xoff = rec * a.x_ld;
+        }
+        return w;
+    };
+    auto request_t = [&](const Where& w) -> int {
+        if (a.mode == 0) return a.tvec ? (w.valid ? (int)a.tvec[w.row] : 0) : a.t_scalar;
+        return a.t_list[w.kk];
+    };
+    float raw[KS0 * 8];
+    auto request_x = [&](const Where& w) {
+        const int64_t cs = (a.mode == 0) ? a.x_cs : 1;
+        static_for<KS0>([&](auto ic) {
+            constexpr int ks = decltype(ic)::value;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = feat(ks, hh, j);
+                raw[ks * 8 + j] = (w.valid && f < a.D) ? a.x[w.xoff + (int64_t)f * cs] : 0.0f;
+            }
+        });
+    };
+    auto request_emb = [&](int t) {  // proj accumulators <- emb[t] + proj bias (MODEL:614), straight from the table
+        const float* er = a.embb + (int64_t)t * a.emb_ld;
+        static_for<kDimT / 32>([&](auto ic) { acc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value + 4 * hh); });
+    };
+
+    Where cur = locate(blockIdx.x);
+    int t_cur = request_t(cur);
+    request_x(cur);
+    request_emb(t_cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        stamp(-1);
+        // ---- input fragments: bf16 of x (mode 0) or of x_t = a x + b noise_p (mode 1, GMD:302 / TF:86)
+        bf16x8 XI[KS0];
+        {
+            const float2 ab = (a.mode == 1) ? scoef[cur.kk] : make_float2(1.0f, 0.0f);
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f = feat(ks, hh, j);
-                    const float v = (valid && f < a.D) ? sr.sqrt_acp * a.x[rec * a.x_ld + f] + sr.sqrt_1m_acp * a.noise[p_idx * a.D + f] : 0.0f;
+                    float v = raw[ks * 8 + j];
+                    if (a.mode == 1) v = (cur.valid && f < a.D) ? ab.x * v + ab.y * snoise[cur.pp * a.D + f] : 0.0f;
                     XI[ks][j] = (__bf16)v;
                 }
             });
         }
-        // ---- proj (D -> 128): accumulators start at bias + emb[t]   (MODEL:614)
-        const float* er = a.emb + (int64_t)t_row * a.emb_ld;
-        static_for<kDimT / 32>([&](auto ic) {
-            constexpr int nt = decltype(ic)::value;
-            acc[nt] = load16(sbias + 32 * nt + 4 * hh);
-            const f32x16 e = load16(er + 32 * nt + 4 * hh);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] += e[r];
-        });
+        const Where nxt = locate(tile + gridDim.x);
+        const int t_nxt = request_t(nxt);
         const float* sb = sbias + kDimT;
-        stamp(0);  // prologue (input loads, emb gather)
+        stamp(0);  // prologue
+        // ---- proj (D -> 128)
         bf16x8 XP[kDimT / 16];  // proj output; not in X: the 128 -> H layer reads its last k-step while X is rewritten
         dense<KS0, kDimT / 32, 1, false, NTH>(p, w0, w1, XI, XP, acc, sb, hh);
         // ---- hidden layers (MODEL:300-301); activations are rewritten in place
@@ -300,19 +344,30 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             dense<KSH, NTH, NTH * KSH / kChunkFrags, true, NTH>(p, w0, w1, X, X, acc, sb, hh);
         }
         stamp(3);  // H -> H layers
-        // (after the last hidden layer acc[0] holds the head's bias for output tile 0: the bias image continues)
-        // ---- head (H -> D): one chunk (32 k-steps, one accumulator) per output tile   (MODEL:303)
+        // ---- head (H -> D), MODEL:303.  Only four accumulators are busy now: the next tile's record and its
+        // ---- emb rows are requested here and land (in the free accumulators) while the head runs.
+        request_x(nxt);
+        request_emb(t_nxt);
         float sq = 0.0f;
         static_for<DT>([&](auto tc) {
             constexpr int nt = decltype(tc)::value;
-            if constexpr (nt > 0) acc[0] = load16(sb + 32 * nt + 4 * hh);
-            consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) { acc[0] = MFMA(w, X[decltype(ic)::value], acc[0]); });
+            acc[HA] = load16(sb + 32 * nt + 4 * hh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[HA + 1][r] = acc[HA + 2][r] = acc[HA + 3][r] = 0.0f;
+            // four independent accumulation chains over k (a single chain would wait out the MFMA latency)
+            consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) {
+                constexpr int ks = decltype(ic)::value;
+                acc[HA + (ks & 3)] = MFMA(w, X[ks], acc[HA + (ks & 3)]);
+            });
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = (acc[HA][r] + acc[HA + 1][r]) + (acc[HA + 2][r] + acc[HA + 3][r]);
             if (a.mode == 0) {
-                if (valid) {
+                if (cur.valid) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
-                        if (f < a.D) a.out[row * a.o_rs + (int64_t)f * a.o_cs] = acc[0][r];
+                        if (f < a.D) a.out[cur.row * a.o_rs + (int64_t)f * a.o_cs] = o[r];
                     }
                 }
             } else {
@@ -320,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int f = 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
                     if (f < a.D) {
-                        const float d = a.noise[p_idx * a.D + f] - acc[0][r];
+                        const float d = snoise[cur.pp * a.D + f] - o[r];
                         sq += d * d;
                     }
                 }
@@ -328,8 +383,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         });
         if (a.mode == 1) {  // TF:92-95: mean over the numeric features
             sq += __shfl_xor(sq, 32);
-            if (valid && hh == 0) a.score[row] = sq / (float)a.D;
+            if (cur.valid && hh == 0) a.score[cur.row] = sq / (float)a.D;
         }
+        cur = nxt;
+        t_cur = t_nxt;
         stamp(4);  // head + output
         if constexpr (STAMP) st_sum[5] += 1;
     }
@@ -338,6 +395,13 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_sum[i]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches must land before the LDS is released
+}
+
+__global__ void k_add_bias_rows(float* dst, const float* src, const float* bias, int rows, int ld, int n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)rows * ld; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        dst[i] = src[i] + (c < n ? bias[c] : 0.0f);
+    }
 }
 
 // order 0: k-step-major (fragment = ks * NT + nt), order 1: tile-major (fragment = nt * KS + ks)
@@ -406,7 +470,9 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     a.wfrag = reinterpret_cast<const unsigned char*>(c->d_wfrag);
     a.bias = c->d_bias_all;
     a.n_bias = L.n_bias;
-    a.emb = c->d_emb;
+    a.embb = c->d_embb;
+    a.n_noise = (a.mode == 1) ? a.P * c->D : 0;
+    if (a.n_noise > kMaxNoise) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused Tartan-Federer kernel: P * Nn = %d exceeds %d", a.n_noise, kMaxNoise);
     a.emb_ld = c->emb_ld;
     a.n_hidden = L.n_hidden;
     a.total_chunks = L.total_chunks;
@@ -425,7 +491,7 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
         }
         MTK_HIP(hipMemsetAsync(d_st, 0, 64, s));
         a.stamps = d_st;
-        const size_t lds2 = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H) * 4 + 15) & ~(size_t)15);
+        const size_t lds2 = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H + a.n_noise + 2 * kMaxTF) * 4 + 15) & ~(size_t)15);
         hipLaunchKernelGGL((k_fused<512, 1, true>), dim3(grid), dim3(256), lds2, s, a);
         MTK_HIP(hipStreamSynchronize(s));
         unsigned long long h[8];
@@ -435,7 +501,7 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
                 h[2] / n, h[3] / n, h[4] / n);
         return MTK_OK;
     }
-    const size_t lds = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H) * 4 + 15) & ~(size_t)15);
+    const size_t lds = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H + a.n_noise + 2 * kMaxTF) * 4 + 15) & ~(size_t)15);
     return launch<512>(L, a, grid, lds, s);
 }
 
@@ -444,6 +510,8 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
 void mtk_free_fused(mtk_ctx* c) {
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_bias_all) (void)hipFree(c->d_bias_all);
+    if (c->d_embb) (void)hipFree(c->d_embb);
+    c->d_embb = nullptr;
     c->d_wfrag = nullptr;
     c->d_bias_all = nullptr;
     c->wfrag_bytes = 0;
@@ -469,6 +537,8 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
     c->wfrag_bytes = (size_t)L.total_chunks * kChunkBytes;
     MTK_HIP(hipMalloc(&c->d_wfrag, c->wfrag_bytes));
     MTK_HIP(hipMalloc(&c->d_bias_all, sizeof(float) * L.n_bias));
+    MTK_HIP(hipMalloc(&c->d_embb, sizeof(float) * (size_t)c->T * c->emb_ld));
+    hipLaunchKernelGGL(k_add_bias_rows, dim3(256), dim3(256), 0, s, c->d_embb, c->d_emb, c->proj.b32, c->T, c->emb_ld, kDimT);
     MTK_HIP(hipMemsetAsync(c->d_wfrag, 0, c->wfrag_bytes, s));
     MTK_HIP(hipMemsetAsync(c->d_bias_all, 0, sizeof(float) * L.n_bias, s));
     unsigned short* dst = reinterpret_cast<unsigned short*>(c->d_wfrag);
