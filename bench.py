@@ -45,7 +45,7 @@ def cpu_baseline(params, Nn, T, seed, seconds_target=10.0):
         orc.tf_score(s, Nn, params, x[:512], noise, 3)  # warm-up
         t0 = time.perf_counter()
         n_t = 0
-        while time.perf_counter() - t0 < seconds_target and n_t < 64:
+        while time.perf_counter() - t0 < seconds_target and n_t < 2000:
             orc.tf_score(s, Nn, params, x, noise, (37 * n_t + 1) % T)
             n_t += 1
         dt = time.perf_counter() - t0
