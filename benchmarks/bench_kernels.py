@@ -45,6 +45,7 @@ def main():
     torch.manual_seed(0)
     net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([a.hidden] * 4, 0.0))
     d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
+    d.rng = "philox"  # in-kernel noise => MTK_MATH_FAST
     eng = d.engine()
     g = torch.Generator().manual_seed(20250821)
     x0 = torch.cat([torch.randn((B, Nn), generator=g).clamp(-5.2, 5.2)] + [torch.randint(0, int(k), (B, 1), generator=g).float() for k in K], 1).to(dev)
@@ -59,17 +60,21 @@ def main():
         print(json.dumps({"kernel": name, "rows": B, "ms": secs * 1e3, "bytes_per_row": bytes_per_row, "GB/s": gbs,
                           "frac_of_8TBs": gbs / HBM_PEAK, "rows_per_s": B / secs, "note": note}), flush=True)
 
-    # q_sample, Philox noise: read x0 (Nn + C floats) + t; write model input D floats + C idx
-    b_q = (Nn + C) * 4 + 8 + D * 4 + C * 4
-    emit("mtk_q_sample (Philox)", timeit(lambda: eng.q_sample(x0, t, None, None, x_in, (1, B), idx, seed=1)), b_q)
-    # loss_rows, Philox eps: read out D floats + x0 + idx + t; write 2 floats
-    b_l = D * 4 + (Nn + C) * 4 + C * 4 + 8 + 8
-    emit("mtk_loss_rows (Philox)", timeit(lambda: eng.loss_rows(out, (1, B), x0, idx, None, t, lm, lg, seed=1)), b_l)
-    # reverse step: z fp64 rw + eps_hat + out_cat + idx rw + next model input
-    z = torch.randn((Nn, B), device=dev, dtype=torch.float64)
-    zi = torch.randint(0, 10, (C, B), device=dev, dtype=torch.int32)
-    b_s = Nn * 8 * 2 + Nn * 4 + S * 4 + C * 4 * 2 + D * 4
-    emit("mtk_p_sample_step (Philox)", timeit(lambda: eng.p_sample_step(B, 500, False, out, (1, B), z, zi, None, None, x_in, (1, B), seed=1)), b_s)
+    for math in ("fast", "reference"):
+      eng.set_math(math)
+      tag = f"Philox, math={math}"
+      # q_sample, Philox noise: read x0 (Nn + C floats) + t; write model input D floats + C idx
+      b_q = (Nn + C) * 4 + 8 + D * 4 + C * 4
+      emit(f"mtk_q_sample ({tag})", timeit(lambda: eng.q_sample(x0, t, None, None, x_in, (1, B), idx, seed=1)), b_q)
+      # loss_rows, Philox eps: read out D floats + x0 + idx + t; write 2 floats
+      b_l = D * 4 + (Nn + C) * 4 + C * 4 + 8 + 8
+      emit(f"mtk_loss_rows ({tag})", timeit(lambda: eng.loss_rows(out, (1, B), x0, idx, None, t, lm, lg, seed=1)), b_l)
+      # reverse step: z fp64 rw + eps_hat + out_cat + idx rw + next model input
+      z = torch.randn((Nn, B), device=dev, dtype=torch.float64)
+      zi = torch.randint(0, 10, (C, B), device=dev, dtype=torch.int32)
+      b_s = Nn * 8 * 2 + Nn * 4 + S * 4 + C * 4 * 2 + D * 4
+      emit(f"mtk_p_sample_step ({tag})", timeit(lambda: eng.p_sample_step(B, 500, False, out, (1, B), z, zi, None, None, x_in, (1, B), seed=1)), b_s)
+    eng.set_math("fast")
     # denoiser alone, shape M
     for prec in ("bf16", "fp32"):
         if prec == "bf16" and a.hidden != 512:
@@ -80,7 +85,6 @@ def main():
         print(json.dumps({"kernel": f"mtk_mlp_forward {prec} (shape M, 4x{a.hidden})", "rows": B, "ms": secs * 1e3, "TFLOP/s": B * fl / secs / 1e12,
                           "frac_of_peak": B * fl / secs / 1e12 / peak, "rows_per_s": B / secs}), flush=True)
     # whole mixed_loss (Philox) and reverse row-steps per second
-    d.rng = "philox"
     for prec in ("bf16", "fp32"):
         if prec == "bf16" and a.hidden != 512:
             continue

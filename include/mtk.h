@@ -66,6 +66,16 @@ enum mtk_precision {
     MTK_PREC_BF16 = 1  /* bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16), fused over layers */
 };
 
+/* Arithmetic of the diffusion kernels (mtk_q_sample, mtk_loss_rows, mtk_p_sample_step, mtk_sample_init). */
+enum mtk_math {
+    MTK_MATH_REFERENCE = 0, /* accurate expf/logf, every fp32 op rounded as the reference's eager ops, the block
+                               log-sum-exp restated as torch-CPU computes it (fp64 cumulative scan + fp32 log-sub-exp,
+                               DU:250-289): the parity mode, default */
+    MTK_MATH_FAST = 1       /* hardware exp/log, exact per-block log-sum-exp, closed forms for the true posterior and
+                               the prior: same formulas without the reference's fp32 cancellation noise; meant for
+                               runs with in-kernel Philox noise (no reference random stream to match) */
+};
+
 const char* mtk_last_error(void);
 int mtk_version(void);
 
@@ -76,6 +86,8 @@ int mtk_version(void);
 int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K_host, const float* logK_host,
                    const double* tables_host, mtk_ctx** out);
 void mtk_ctx_destroy(mtk_ctx* ctx);
+/* No reference counterpart: selects enum mtk_math for this context's diffusion kernels. */
+int mtk_ctx_set_math(mtk_ctx* ctx, int mode);
 
 /* Replaces MLPDiffusion's parameter storage (MODEL:548-594).  W[i] / b[i] are device pointers to
  * fp32 PyTorch-layout weights [out_i][in_i] / [out_i], in this order:

@@ -31,6 +31,7 @@ _SIGS = {
     "mtk_version": (C.c_int, []),
     "mtk_ctx_create": (C.c_int, [_i32, _i32, _i32, _i32, _p, _p, _p, C.POINTER(_p)]),
     "mtk_ctx_destroy": (None, [_p]),
+    "mtk_ctx_set_math": (C.c_int, [_p, _i32]),
     "mtk_mlp_set_weights": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p]),
     "mtk_mlp_forward": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i32, _p, _i64, _i64, _i32, _p]),
     "mtk_q_sample": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _u64, _u64, _p]),

@@ -56,6 +56,7 @@ struct mtk_ctx {
     SchedRow* d_rows = nullptr;
     int32_t* d_off = nullptr;
     float* d_logK = nullptr;
+    bool fast_math = false;  // MTK_MATH_FAST: diffusion kernels on hardware transcendentals, exact block LSE
     // denoiser
     bool have_weights = false;
     int dim_t = 0, n_hidden = 0;

@@ -57,14 +57,64 @@ __device__ __forceinline__ float lse_sub(float a, float b) {
     const float m = fmaxf(a, b);
     return logf(expf(a - m) - expf(b - m)) + m;
 }
-// torch-CPU logcumsumexp step (fp64 running value): r <- log1p(exp(min - max)) + max
-__device__ __forceinline__ void scan_push(double& r, float x) {
-    const double xd = (double)x;
-    const double hi = fmax(xd, r), lo = fmin(xd, r);
-    if (lo != hi || isfinite(lo)) r = log1p(exp(lo - hi)) + hi; else r = xd;
-}
 // GMD:866  -log(-log(u + 1e-30) + 1e-30)
 __device__ __forceinline__ float gumbel(float u) { return -logf(-logf(u + MTK_TINY) + MTK_TINY); }
+// same map on the hardware log (v_log_f32): used only for in-kernel Philox noise, where no reference
+// random stream exists to be bit-compatible with
+__device__ __forceinline__ float gumbel_fast(float u) { return -__logf(-__logf(u + MTK_TINY) + MTK_TINY); }
+
+// Sequential reader of one Philox stream of a record: one 10-round Philox call per four values.
+struct PhiloxU {
+    uint64_t seed, row;
+    uint32_t stream;
+    int have;
+    uint4 r;
+    __device__ __forceinline__ PhiloxU(uint64_t s, uint64_t rw, uint32_t st) : seed(s), row(rw), stream(st), have(-1) {}
+    __device__ __forceinline__ float uniform(int j) {
+        if ((j >> 2) != have) {
+            have = j >> 2;
+            r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+        }
+        const uint32_t w = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
+        return mtk_u01(w);
+    }
+};
+struct PhiloxN {
+    uint64_t seed, row;
+    uint32_t stream;
+    int have;
+    float n0, n1, n2, n3;
+    __device__ __forceinline__ PhiloxN(uint64_t s, uint64_t rw, uint32_t st) : seed(s), row(rw), stream(st), have(-1) {}
+    __device__ __forceinline__ float normal(int j) {
+        if ((j >> 2) != have) {
+            have = j >> 2;
+            const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+            mtk_normal2(r.x, r.y, n0, n1);
+            mtk_normal2(r.z, r.w, n2, n3);
+        }
+        return (j & 2) ? ((j & 1) ? n3 : n2) : ((j & 1) ? n1 : n0);
+    }
+};
+
+// Whole-row cumulative log-sum-exp of DU:268-289, one block at a time.  torch-CPU runs the recurrence
+// r <- max + log1p(exp(min - max)) in fp64 over every column and rounds r to fp32 at the block boundaries.
+// The same fp64 value (to ~1e-16, i.e. the same fp32 rounding) is obtained with ONE fp64 exp per column:
+// b = sum_j exp(x_j - m) with m the block maximum, L = m + log(b), r <- logaddexp(r, L) once per block.
+struct RowScan {
+    double run;   // fp64 running log-cum-sum-exp
+    float prev;   // its fp32 rounding at the previous block boundary
+    __device__ __forceinline__ RowScan() : run(-INFINITY), prev(-INFINITY) {}
+    // finishes a block whose shifted sum is b (relative to m); returns the reference's fp32 block LSE
+    __device__ __forceinline__ float close_block(double b, float m) {
+        const double L = (double)m + log(b);
+        const double hi = fmax(L, run), lo = fmin(L, run);
+        run = (lo != hi || isfinite(lo)) ? log1p(exp(lo - hi)) + hi : L;
+        const float cur = (float)run;
+        const float out = lse_sub(cur, prev);
+        prev = cur;
+        return out;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // q_sample: a4 (GMD:302) + a5 (DU:209) + a6 (GMD:742) + a7 (GMD:852, 873)
@@ -90,8 +140,10 @@ __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
         const SchedRow sr = s.rows[t];
         const float* xr = a.x0 + row * a.x0_ld;
         float* xo = a.x_in + row * a.xi_rs;
+        PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
+        PhiloxU pu(a.seed, a.row0 + row, MTK_STREAM_U);
         for (int j = 0; j < Nn; ++j) {
-            const float e = a.eps ? a.eps[row * Nn + j] : mtk_philox_normal(a.seed, a.row0 + row, MTK_STREAM_EPS, j);
+            const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
             xo[j * a.xi_cs] = sr.sqrt_acp * xr[j] + sr.sqrt_1m_acp * e;
         }
         for (int k = 0; k < C; ++k) {
@@ -103,8 +155,8 @@ __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
             float best = -INFINITY;
             int arg = 0;
             for (int i = 0; i < Kk; ++i) {
-                const float uu = a.u ? a.u[row * S + o + i] : mtk_philox_uniform(a.seed, a.row0 + row, MTK_STREAM_U, o + i);
-                const float v = gumbel(uu) + (i == c0 ? hot : cold);
+                const float g = a.u ? gumbel(a.u[row * S + o + i]) : gumbel_fast(pu.uniform(o + i));
+                const float v = g + (i == c0 ? hot : cold);
                 if (v > best || i == 0) { best = v; arg = i; }
             }
             a.xt_idx[(int64_t)k * a.B + row] = arg;
@@ -138,9 +190,10 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
         const int t = (int)a.t[row];
         const float* mo = a.mo + row * a.mo_rs;
         if (a.loss_gauss && Nn > 0) {  // mean_d (eps - eps_hat)^2
+            PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
             float acc = 0.0f;
             for (int j = 0; j < Nn; ++j) {
-                const float e = a.eps ? a.eps[row * Nn + j] : mtk_philox_normal(a.seed, a.row0 + row, MTK_STREAM_EPS, j);
+                const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
                 const float df = e - mo[j * a.mo_cs];
                 acc += df * df;
             }
@@ -151,8 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
         const SchedRow st = s.rows[t];
         const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
         const float* xr = a.x0 + row * a.x0_ld;
-        double run_t = -INFINITY, run_m = -INFINITY;  // fp64 running log-cum-sum-exp over the WHOLE row
-        float cum_t0 = -INFINITY, cum_m0 = -INFINITY;
+        RowScan scan_t, scan_m;  // true and model posterior: cumulative over the WHOLE row
         float kl = 0.0f, nll = 0.0f, prior = 0.0f;
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
@@ -169,31 +221,37 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
             const float e_cold = (t == 0) ? MTK_LOG_TINY : lae(MTK_LOG_TINY + s1.log_acp, ce);
             // log-softmax of the block's logits (GMD:778)
             float mx = -INFINITY;
-            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            int amax = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float v = mc[i * a.mo_cs];
+                if (v > mx || i == 0) { mx = v; amax = i; }
+            }
             float sum = 0.0f;
             for (int i = 0; i < Kk; ++i) sum += expf(mc[i * a.mo_cs] - mx);
             const float lsum = logf(sum);
-            for (int i = 0; i < Kk; ++i) {
-                const float qo = (i == ct) ? q_hot : q_cold;
-                const float un_t = ((i == c0) ? e_hot : e_cold) + qo;
+            // block maxima of the two unnormalised posteriors (the shift of the fp64 sums): the model term is
+            // increasing in the logit, so its maximum sits at the arg-max logit or at the sampled x_t
+            auto un_model = [&](int i) {
                 const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
                 const float ev = (t == 0) ? lsm : lae(lsm + s1.log_acp, ce);
-                scan_push(run_t, un_t);
-                scan_push(run_m, ev + qo);
+                return ev + ((i == ct) ? q_hot : q_cold);
+            };
+            const float m_m = fmaxf(un_model(amax), un_model(ct));
+            float m_t = fmaxf(((ct == c0) ? e_hot : e_cold) + q_hot, e_hot + ((ct == c0) ? q_hot : q_cold));
+            if (Kk > 2 || (Kk == 2 && ct == c0)) m_t = fmaxf(m_t, e_cold + q_cold);
+            double b_t = 0.0, b_m = 0.0;
+            for (int i = 0; i < Kk; ++i) {
+                const float un_t = ((i == c0) ? e_hot : e_cold) + ((i == ct) ? q_hot : q_cold);
+                b_t += exp((double)un_t - (double)m_t);
+                b_m += exp((double)un_model(i) - (double)m_m);
             }
-            const float cum_t1 = (float)run_t, cum_m1 = (float)run_m;
-            const float lse_t = lse_sub(cum_t1, cum_t0), lse_m = lse_sub(cum_m1, cum_m0);
-            cum_t0 = cum_t1;
-            cum_m0 = cum_m1;
+            const float lse_t = scan_t.close_block(b_t, m_t), lse_m = scan_m.close_block(b_m, m_m);
             // prior term q(x_T | x_0) vs uniform (GMD:887)
             const float cT = srT.log_1m_acp - logK;
             const float p_hot = lae(0.0f + srT.log_acp, cT), p_cold = lae(MTK_LOG_TINY + srT.log_acp, cT);
             for (int i = 0; i < Kk; ++i) {
-                const float qo = (i == ct) ? q_hot : q_cold;
-                const float lt = (((i == c0) ? e_hot : e_cold) + qo) - lse_t;
-                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
-                const float ev = (t == 0) ? lsm : lae(lsm + s1.log_acp, ce);
-                const float lm = (ev + qo) - lse_m;
+                const float lt = (((i == c0) ? e_hot : e_cold) + ((i == ct) ? q_hot : q_cold)) - lse_t;
+                const float lm = un_model(i) - lse_m;
                 kl += expf(lt) * (lt - lm);
                 nll += expf((i == c0) ? 0.0f : MTK_LOG_TINY) * lm;
                 const float qT = (i == c0) ? p_hot : p_cold;
@@ -233,6 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const float* mo = a.mo + row * a.mo_rs;
         float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
+        PhiloxN pn(a.seed, a.row0 + row, stream_n);
+        PhiloxU pu(a.seed, a.row0 + row, stream_u);
         for (int j = 0; j < Nn; ++j) {
             const float eh = mo[j * a.mo_cs];
             double* zp = a.z + (int64_t)j * a.B + row;
@@ -242,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
                 nz = a.noise_f64 ? reinterpret_cast<const double*>(a.noise)[row * Nn + j]
                                  : (double)reinterpret_cast<const float*>(a.noise)[row * Nn + j];
             } else {
-                nz = (double)mtk_philox_normal(a.seed, a.row0 + row, stream_n, j);
+                nz = (double)pn.normal(j);
             }
             double mean;
             if (a.first) {  // z is still fp32: torch forms the mean in fp32 (SURVEY finding 0.4)
@@ -258,8 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
             *zp = zn;
             if (xo) xo[j * a.xi_cs] = (float)zn;
         }
-        double run = -INFINITY;
-        float cum0 = -INFINITY;
+        RowScan scan;
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
             const float logK = s.logK[k];
@@ -269,26 +328,29 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
             const float q_hot = lae(0.0f + a.log_alpha, cq), q_cold = lae(MTK_LOG_TINY + a.log_alpha, cq);
             const float ce = a.log_1m_acp_prev - logK;
             float mx = -INFINITY;
-            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            int amax = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float v = mc[i * a.mo_cs];
+                if (v > mx || i == 0) { mx = v; amax = i; }
+            }
             float sum = 0.0f;
             for (int i = 0; i < Kk; ++i) sum += expf(mc[i * a.mo_cs] - mx);
             const float lsum = logf(sum);
-            for (int i = 0; i < Kk; ++i) {
+            auto un = [&](int i) {
                 const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
                 const float ev = (t == 0) ? lsm : lae(lsm + a.log_acp_prev, ce);
-                scan_push(run, ev + ((i == cz) ? q_hot : q_cold));
-            }
-            const float cum1 = (float)run;
-            const float lse = lse_sub(cum1, cum0);
-            cum0 = cum1;
+                return ev + ((i == cz) ? q_hot : q_cold);
+            };
+            const float m = fmaxf(un(amax), un(cz));
+            double b = 0.0;
+            for (int i = 0; i < Kk; ++i) b += exp((double)un(i) - (double)m);
+            const float lse = scan.close_block(b, m);
             float best = -INFINITY;
             int arg = 0;
             for (int i = 0; i < Kk; ++i) {
-                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
-                const float ev = (t == 0) ? lsm : lae(lsm + a.log_acp_prev, ce);
-                const float logp = (ev + ((i == cz) ? q_hot : q_cold)) - lse;
-                const float uu = a.u ? a.u[row * S + o + i] : mtk_philox_uniform(a.seed, a.row0 + row, stream_u, o + i);
-                const float v = gumbel(uu) + logp;
+                const float logp = un(i) - lse;
+                const float g = a.u ? gumbel(a.u[row * S + o + i]) : gumbel_fast(pu.uniform(o + i));
+                const float v = g + logp;
                 if (v > best || i == 0) { best = v; arg = i; }
             }
             a.z_idx[(int64_t)k * a.B + row] = arg;
@@ -315,8 +377,10 @@ __global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         float* xo = a.x_in + row * a.xi_rs;
+        PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_Z0);
+        PhiloxU pu(a.seed, a.row0 + row, MTK_STREAM_U0);
         for (int j = 0; j < Nn; ++j) {
-            const float v = a.z0 ? a.z0[row * Nn + j] : mtk_philox_normal(a.seed, a.row0 + row, MTK_STREAM_Z0, j);
+            const float v = a.z0 ? a.z0[row * Nn + j] : pn.normal(j);
             a.z[(int64_t)j * a.B + row] = (double)v;
             xo[j * a.xi_cs] = v;
         }
@@ -325,8 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
             float best = -INFINITY;
             int arg = 0;
             for (int i = 0; i < Kk; ++i) {
-                const float uu = a.u0 ? a.u0[row * S + o + i] : mtk_philox_uniform(a.seed, a.row0 + row, MTK_STREAM_U0, o + i);
-                const float v = gumbel(uu) + 0.0f;
+                const float v = (a.u0 ? gumbel(a.u0[row * S + o + i]) : gumbel_fast(pu.uniform(o + i))) + 0.0f;
                 if (v > best || i == 0) { best = v; arg = i; }
             }
             a.z_idx[(int64_t)k * a.B + row] = arg;
@@ -343,6 +406,222 @@ __global__ __launch_bounds__(kBlock) void k_sample_decode(int64_t B, int Nn, int
         const int64_t row = i / W;
         const int c = (int)(i - row * W);
         out[i] = (c < Nn) ? z[(int64_t)c * B + row] : (double)z_idx[(int64_t)(c - Nn) * B + row];
+    }
+}
+
+// ================================================================================================
+// MTK_MATH_FAST variants.  Same formulas on the hardware transcendentals (v_exp_f32 / v_log_f32) and
+// without the reference's rounding artefacts:
+//   * the block normaliser is the exact per-block log-sum-exp m + log(sum exp(x - m)) in fp32 — the
+//     reference's cumulative-scan value differs from it by zero-mean fp32 cancellation noise
+//     (tests/test_conditioning.py), so batch means agree and per-record values are closer to exact;
+//   * the true posterior takes three distinct values per block (x_0's column, x_t's column, the rest) and
+//     the prior two, so both are closed forms per block; only the model posterior is per column;
+//   * the reverse step skips the normaliser: argmax(g + logp) = argmax(g + unnormalised logp) per block.
+// Used for throughput runs (in-kernel Philox noise has no reference stream to be bit-compatible with).
+// ================================================================================================
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float flog(float x) { return __logf(x); }
+__device__ __forceinline__ float lae_f(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m + flog(fexp(a - m) + fexp(b - m));
+}
+__device__ __forceinline__ void normal2_fast(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * 0x1p-24f;
+    const float u2 = (float)(b >> 8) * 0x1p-24f;
+    const float r = __fsqrt_rn(-2.0f * flog(u1));
+    n0 = r * __cosf(6.283185307179586f * u2);
+    n1 = r * __sinf(6.283185307179586f * u2);
+}
+struct PhiloxNF {
+    uint64_t seed, row;
+    uint32_t stream;
+    int have;
+    float n0, n1, n2, n3;
+    __device__ __forceinline__ PhiloxNF(uint64_t s, uint64_t rw, uint32_t st) : seed(s), row(rw), stream(st), have(-1) {}
+    __device__ __forceinline__ float normal(int j) {
+        if ((j >> 2) != have) {
+            have = j >> 2;
+            const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+            normal2_fast(r.x, r.y, n0, n1);
+            normal2_fast(r.z, r.w, n2, n3);
+        }
+        return (j & 2) ? ((j & 1) ? n3 : n2) : ((j & 1) ? n1 : n0);
+    }
+};
+
+template <bool LDS_ROWS>
+__global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
+    const Staged s = stage_tables<LDS_ROWS>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int t = (int)a.t[row];
+        const SchedRow sr = s.rows[t];
+        const float* xr = a.x0 + row * a.x0_ld;
+        float* xo = a.x_in + row * a.xi_rs;
+        PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
+        PhiloxU pu(a.seed, a.row0 + row, MTK_STREAM_U);
+        for (int j = 0; j < Nn; ++j) {
+            const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
+            xo[j * a.xi_cs] = sr.sqrt_acp * xr[j] + sr.sqrt_1m_acp * e;
+        }
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const int c0 = (int)(long long)xr[Nn + k];
+            const float c = sr.log_1m_acp - s.logK[k];
+            const float hot = lae_f(0.0f + sr.log_acp, c);
+            const float cold = lae_f(MTK_LOG_TINY + sr.log_acp, c);
+            float best = -INFINITY;
+            int arg = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float uu = a.u ? a.u[row * S + o + i] : pu.uniform(o + i);
+                const float v = gumbel_fast(uu) + (i == c0 ? hot : cold);
+                if (v > best || i == 0) { best = v; arg = i; }
+            }
+            a.xt_idx[(int64_t)k * a.B + row] = arg;
+            for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
+    }
+}
+
+template <bool LDS_ROWS>
+__global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
+    const Staged s = stage_tables<LDS_ROWS>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
+    const SchedRow srT = s.rows[T - 1];
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int t = (int)a.t[row];
+        const float* mo = a.mo + row * a.mo_rs;
+        if (a.loss_gauss && Nn > 0) {
+            PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
+            float acc = 0.0f;
+            for (int j = 0; j < Nn; ++j) {
+                const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
+                const float df = e - mo[j * a.mo_cs];
+                acc += df * df;
+            }
+            a.loss_gauss[row] = acc / (float)Nn;
+        }
+        if (!a.loss_multi || C == 0) continue;
+        const SchedRow st = s.rows[t];
+        const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
+        const float* xr = a.x0 + row * a.x0_ld;
+        float kl = 0.0f, nll = 0.0f, prior = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const float logK = s.logK[k];
+            const int c0 = (int)(long long)xr[Nn + k];
+            const int ct = a.xt_idx[(int64_t)k * a.B + row];
+            const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+            const float cq = st.log_1m_alpha - logK;
+            const float q_hot = lae_f(0.0f + st.log_alpha, cq), q_cold = lae_f(MTK_LOG_TINY + st.log_alpha, cq);
+            const float ce = s1.log_1m_acp - logK;
+            const float e_hot = (t == 0) ? 0.0f : lae_f(0.0f + s1.log_acp, ce);
+            const float e_cold = (t == 0) ? MTK_LOG_TINY : lae_f(MTK_LOG_TINY + s1.log_acp, ce);
+            // true posterior: three distinct unnormalised values, closed-form normaliser
+            const float v_c0 = e_hot + ((c0 == ct) ? q_hot : q_cold);  // column of x_0
+            const float v_ct = e_cold + q_hot;                          // column of x_t (when != x_0)
+            const float v_cc = e_cold + q_cold;                         // every other column
+            const int n_cc = Kk - ((c0 == ct) ? 1 : 2);
+            const float m_t = fmaxf(v_c0, fmaxf(v_ct, v_cc));
+            float b_t = fexp(v_c0 - m_t) + (float)n_cc * fexp(v_cc - m_t);
+            if (c0 != ct) b_t += fexp(v_ct - m_t);
+            const float lse_t = m_t + flog(b_t);
+            const float lt_c0 = v_c0 - lse_t, lt_ct = v_ct - lse_t, lt_cc = v_cc - lse_t;
+            const float w_c0 = fexp(lt_c0), w_ct = fexp(lt_ct), w_cc = fexp(lt_cc);
+            // model posterior: log-softmax of the logits, one pass for the normaliser and the KL sums
+            float mx = -INFINITY;
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            float sum = 0.0f;
+            for (int i = 0; i < Kk; ++i) sum += fexp(mc[i * a.mo_cs] - mx);
+            const float lsum = flog(sum);
+            // shift of the model block: its maximum is at the largest logit or at x_t's column; bound it by
+            // the largest logit's value with q_hot (>= every column's value)
+            const float ev_top = (t == 0) ? -lsum : lae_f(-lsum + s1.log_acp, ce);
+            const float m_m = ev_top + q_hot;
+            float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
+            for (int i = 0; i < Kk; ++i) {
+                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae_f(lsm + s1.log_acp, ce);
+                const float un = ev + ((i == ct) ? q_hot : q_cold);
+                b_m += fexp(un - m_m);
+                const float lt = (i == c0) ? lt_c0 : ((i == ct) ? lt_ct : lt_cc);
+                const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
+                acc_kl += w * (lt - un);
+                if (i == c0) un_c0 = un;
+            }
+            const float lse_m = m_m + flog(b_m);
+            const float w_sum = w_c0 + (float)n_cc * w_cc + ((c0 != ct) ? w_ct : 0.0f);
+            kl += acc_kl + lse_m * w_sum;          // sum_i e^{lt_i} (lt_i - (un_i - lse_m))
+            nll += un_c0 - lse_m;                  // log-probability of x_0 (columns weighted 1e-30 dropped)
+            const float cT = srT.log_1m_acp - logK;
+            const float p_hot = lae_f(0.0f + srT.log_acp, cT), p_cold = lae_f(MTK_LOG_TINY + srT.log_acp, cT);
+            prior += fexp(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (fexp(p_cold) * (p_cold + logK));
+        }
+        const float lt = (t == 0) ? -nll : kl;
+        a.loss_multi[row] = (lt * (float)T + prior) / (float)C;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
+    const Staged s = stage_tables<false>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, S = a.d.S, t = a.t;
+    const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)t, stream_u = stream_n + 1u;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const float* mo = a.mo + row * a.mo_rs;
+        float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
+        PhiloxNF pn(a.seed, a.row0 + row, stream_n);
+        PhiloxU pu(a.seed, a.row0 + row, stream_u);
+        for (int j = 0; j < Nn; ++j) {  // the numeric state stays fp64 (SURVEY finding 0.4)
+            const float eh = mo[j * a.mo_cs];
+            double* zp = a.z + (int64_t)j * a.B + row;
+            const double zj = *zp;
+            double nz;
+            if (a.noise) {
+                nz = a.noise_f64 ? reinterpret_cast<const double*>(a.noise)[row * Nn + j]
+                                 : (double)reinterpret_cast<const float*>(a.noise)[row * Nn + j];
+            } else {
+                nz = (double)pn.normal(j);
+            }
+            double mean;
+            if (a.first) {
+                const float zf = (float)zj;
+                const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
+                mean = (double)(a.coef1 * x0h + a.coef2 * zf);
+            } else {
+                const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
+                mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+            }
+            const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
+            *zp = zn;
+            if (xo) xo[j * a.xi_cs] = (float)zn;
+        }
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const float logK = s.logK[k];
+            const int cz = a.z_idx[(int64_t)k * a.B + row];
+            const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+            const float cq = a.log_1m_alpha - logK;
+            const float q_hot = lae_f(0.0f + a.log_alpha, cq), q_cold = lae_f(MTK_LOG_TINY + a.log_alpha, cq);
+            const float ce = a.log_1m_acp_prev - logK;
+            float mx = -INFINITY;
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            float sum = 0.0f;
+            for (int i = 0; i < Kk; ++i) sum += fexp(mc[i * a.mo_cs] - mx);
+            const float lsum = flog(sum);
+            float best = -INFINITY;
+            int arg = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae_f(lsm + a.log_acp_prev, ce);
+                const float uu = a.u ? a.u[row * S + o + i] : pu.uniform(o + i);
+                const float v = gumbel_fast(uu) + (ev + ((i == cz) ? q_hot : q_cold));
+                if (v > best || i == 0) { best = v; arg = i; }
+            }
+            a.z_idx[(int64_t)k * a.B + row] = arg;
+            if (xo)
+                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
     }
 }
 
@@ -371,7 +650,7 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
     MTK_HIP(hipSetDevice(ctx->device));
     QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0};
     const bool lds = ctx->T <= MTK_LDS_T_MAX;
-    auto k = lds ? k_q_sample<true> : k_q_sample<false>;
+    auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true> : k_q_sample_fast<false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -388,7 +667,7 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     MTK_HIP(hipSetDevice(ctx->device));
     LossArgs a{ctx->dev(), B, model_out, mo_rs, mo_cs, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, seed, row0};
     const bool lds = ctx->T <= MTK_LDS_T_MAX;
-    auto k = lds ? k_loss_rows<true> : k_loss_rows<false>;
+    auto k = ctx->fast_math ? (lds ? k_loss_rows_fast<true> : k_loss_rows_fast<false>) : (lds ? k_loss_rows<true> : k_loss_rows<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -419,7 +698,8 @@ extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step,
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
     a.z = z; a.z_idx = z_idx; a.noise = noise; a.noise_f64 = noise_is_f64; a.u = u;
     a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
-    hipLaunchKernelGGL(k_p_sample_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ctx->fast_math ? k_p_sample_step_fast : k_p_sample_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false),
+                       (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
@@ -445,5 +725,12 @@ extern "C" int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const
     hipLaunchKernelGGL(k_sample_decode, dim3(grid_for(B * (ctx->Nn + ctx->C))), dim3(kBlock), 0, (hipStream_t)stream, B,
                        ctx->Nn, ctx->C, z, z_idx, sample);
     MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_ctx_set_math(mtk_ctx* ctx, int mode) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_set_math: null context");
+    if (mode != MTK_MATH_REFERENCE && mode != MTK_MATH_FAST) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_ctx_set_math: unknown mode %d", mode);
+    ctx->fast_math = (mode == MTK_MATH_FAST);
     return MTK_OK;
 }

@@ -105,6 +105,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             self.register_buffer(key, value.float().to(device))
 
         self.rng = "torch"  # "torch": draw like the reference does; "philox": draw inside the kernels
+        self.math = None    # None: "fast" with rng="philox", "reference" otherwise; or force "reference"/"fast"
         self.precision = getattr(denoise_fn, "precision", "fp32")
         self._engine: Engine | None = None
 
@@ -129,6 +130,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                 self._denoise_fn.attach_engine(self._engine)
         if hasattr(self._denoise_fn, "sync_weights"):
             self._denoise_fn.sync_weights()
+        self._engine.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
         return self._engine
 
     def _denoise_cm(self, eng: Engine, x_in: Tensor, t, B: int, out: Tensor) -> None:

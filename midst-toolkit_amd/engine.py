@@ -48,6 +48,10 @@ class Engine:
             except Exception:
                 pass
 
+    def set_math(self, mode: str) -> None:
+        """"reference" (parity, default) or "fast" (hardware transcendentals, exact block log-sum-exp)."""
+        check(_lib.lib().mtk_ctx_set_math(self._h, {"reference": 0, "fast": 1}[mode]))
+
     def _stream(self):
         return _lib.stream_handle(self.device)
 

@@ -8,6 +8,8 @@ Bars (DESIGN.md "Parity"):
   * multinomial loss: batch mean <= 1e-4 relative; per record |d| <= 1e-4 |ref| + 2 * conditioning floor
     (tests/test_conditioning.py shows why a plain per-record 1e-4 is not well-posed).
 """
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -373,3 +375,81 @@ def test_mixed_loss_bf16_mean():
     wm, wg = tt(c["ml_lm_rows"]), tt(c["ml_lg_rows"])
     assert abs(float(lg.mean().cpu()) - float(wg.mean())) <= BF16_TOL * float(wg.mean())
     assert abs(float(lm.mean().cpu()) - float(wm.mean())) <= 5 * BF16_TOL * float(wm.mean())
+
+
+# ------------------------------------------------------------------------------------------------
+# MTK_MATH_FAST (hardware exp/log, exact block log-sum-exp): same formulas, checked against the
+# oracle on injected noise.  Batch means <= 1e-4; per record within the conditioning floor; categorical
+# draws equal except near-ties (margin 2e-4 of the hardware log) rarer than 1e-3.
+# ------------------------------------------------------------------------------------------------
+def _big_mixed_batch(c, B, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    K, Nn, S = c["K"], c["Nn"], c["S"]
+    x0 = torch.cat([torch.randn((B, Nn), generator=g).clamp(-5.2, 5.2)] + [torch.randint(0, int(k), (B, 1), generator=g).float() for k in K], 1)
+    t = torch.randint(0, c["T"], (B,), generator=g)
+    t[:3] = torch.tensor([0, 1, c["T"] - 1])
+    return x0, t, torch.randn((B, Nn), generator=g), torch.rand((B, S), generator=g)
+
+
+@pytest.mark.parametrize("tag", ["M_mixed", "B_ragged"])
+def test_fast_math_against_oracle(tag, monkeypatch):
+    global TIE_MARGIN
+    c = load_case(tag)
+    B, Nn, C, D = 4096, c["Nn"], c["C"], c["D"]
+    d = build(c)
+    d.math = "fast"
+    eng = d.engine()
+    s = orc.make_schedule(c["T"], c["sched"])
+    x0, t, eps, u = _big_mixed_batch(c, B)
+    want_xt, want_idx = orc.q_sample_fused(s, c["K"], Nn, x0, t, eps, u)
+    x_in = torch.empty((D, B), device=dev())
+    idx = torch.empty((C, B), dtype=torch.int32, device=dev())
+    eng.q_sample(x0.to(dev()), t.to(dev()), eps.to(dev()), u.to(dev()), x_in, (1, B), idx)
+    close(x_in[:Nn].t(), want_xt, rtol=1e-6)
+    logits = orc.q_pred(s, orc.log_onehot(x0[:, Nn:].long(), c["K"]), t, orc.log_k_expanded(c["K"]))
+    monkeypatch.setattr(sys.modules[__name__], "TIE_MARGIN", 2e-4)
+    check_categorical(idx.t(), want_idx, logits, u, c["K"])
+    # loss with the oracle's denoiser output and categories injected
+    out = orc.mlp_forward(case_params(c), orc.model_input(want_xt, want_idx, c["K"]), t)
+    wm, wg = orc.loss_rows(s, c["K"], Nn, out, x0, want_idx, eps, t)
+    lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+    eng.loss_rows(colmajor(out), (1, B), x0.to(dev()), want_idx.t().contiguous().int().to(dev()), eps.to(dev()), t.to(dev()), lm, lg)
+    close(lg, wg, rtol=1e-5)
+    assert abs(float(lm.mean().cpu()) - float(wm.mean())) <= RTOL * abs(float(wm.mean()))
+    floor = orc.multinomial_loss_floor(s, c["K"], Nn, out, x0, want_idx, t)
+    err = (lm.cpu().double() - wm.double()).abs()
+    bar = RTOL * wm.abs().double() + 3 * floor + 1e-5  # 3x: the reference and the fast path each sit within ~1.5 floor of the exact value
+    assert bool((err <= bar).all()), float((err / bar).max())
+    # reverse step, t in the middle and t = 0
+    for tt_ in (c["T"] // 2, 0):
+        g = torch.Generator().manual_seed(tt_ + 5)
+        mo = torch.randn((B, D), generator=g) * 2
+        z = torch.randn((B, Nn), generator=g, dtype=torch.float64)
+        zi = torch.stack([torch.randint(0, int(k), (B,), generator=g) for k in c["K"]], 1)
+        n = torch.randn((B, Nn), generator=g, dtype=torch.float64)
+        uu = torch.rand((B, c["S"]), generator=g)
+        want_z = orc.gaussian_p_step(s, mo[:, :Nn], z, tt_, n)
+        tv = torch.full((B,), tt_, dtype=torch.long)
+        logp = orc.q_posterior(s, orc.block_log_softmax(mo[:, Nn:], c["K"]), orc.log_onehot(zi, c["K"]), tv, c["K"])
+        want_zi = orc.gumbel_argmax(logp, uu, c["K"])
+        zd = z.t().contiguous().to(dev())
+        zid = zi.t().contiguous().int().to(dev())
+        eng.p_sample_step(B, tt_, False, colmajor(mo), (1, B), zd, zid, n.to(dev()), uu.to(dev()), None, (1, B))
+        close(zd.t(), want_z, rtol=1e-12, atol=1e-12)
+        check_categorical(zid.t(), want_zi, logp, uu, c["K"])
+
+
+def test_fast_math_philox_statistics():
+    """In-kernel noise + fast math: the loss of a fixed batch agrees with the injected-noise reference
+    value in distribution (different random stream, so only the mean over many records is compared)."""
+    c = load_case("M_mixed")
+    B = 16384
+    d = build(c)
+    x0, t, eps, u = _big_mixed_batch(c, B)
+    lm_ref, lg_ref = d.mixed_loss_rows(x0.to(dev()), timestep=t.to(dev()), noise=eps.to(dev()), uniform=u.to(dev()))
+    d.rng = "philox"
+    lm, lg = d.mixed_loss_rows(x0.to(dev()), timestep=t.to(dev()), seed=123)
+    se_g = float(lg_ref.std()) / B ** 0.5
+    se_m = float(lm_ref.std()) / B ** 0.5
+    assert abs(float(lg.mean()) - float(lg_ref.mean())) < 6 * se_g
+    assert abs(float(lm.mean()) - float(lm_ref.mean())) < 6 * se_m
