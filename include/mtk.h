@@ -161,6 +161,40 @@ int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, d
 int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, double* sample,
                       mtk_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training iteration.  Replaces ClavaDDPMTrainer._train_step /
+ * _anneal_learning_rate / update_ema (models/clavaddpm/trainer.py:58-94, 138-155).
+ *
+ * The five parameter images — 0 weights, 1 gradients, 2 Adam exp_avg, 3 Adam exp_avg_sq, 4 EMA — share the
+ * padded layout of the forward GEMMs and sit back to back in ONE caller-owned device buffer `state` of
+ * 5 * mtk_train_image_elems(ctx) floats, so that a multi-GPU host all-reduces image 1
+ * (state + n .. state + 2n) between mtk_train_step and mtk_train_apply (one exchange per iteration).
+ * ------------------------------------------------------------------------------------------- */
+/* Floats in one image for the weights set by mtk_mlp_set_weights (0 when none are set). */
+int64_t mtk_train_image_elems(mtk_ctx* ctx);
+/* TRAINER:39-51: copies the current weights into image 0 and image 4 (the EMA starts as a deepcopy), zeroes
+ * images 1-3 (fresh AdamW state) and makes the context's fp32 denoiser read its weights from image 0.
+ * freqs_host as in mtk_mlp_set_weights.  mtk_mlp_set_weights detaches. */
+int mtk_train_attach(mtk_ctx* ctx, float* state, const float* freqs_host, mtk_stream stream);
+/* TRAINER:88-91 (zero_grad, mixed_loss GMD:984-1068, backward): fills image 1 with
+ * d[(sum_rows loss_multi + loss_gauss) * inv_global_batch] / d weights for the B rows given and writes the
+ * per-record losses (either pointer may be NULL).  t / eps / u / seed / row0 as in mtk_q_sample.
+ * inv_global_batch = 1 / (rows over all ranks): after a SUM all-reduce image 1 is the gradient of the
+ * global batch mean, which is what the reference's loss.backward() produces on one device. */
+int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                   const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
+                   uint64_t row0, mtk_stream stream);
+/* TRAINER:92 + :133: torch.optim.AdamW.step() (decoupled decay, bias correction, step is 1-based) on images
+ * 0/2/3 from image 1, then EMA image 4 <- ema_rate * image 4 + (1 - ema_rate) * image 0, then the
+ * time-embedding table is rebuilt from the new weights.  The caller owns the learning-rate anneal
+ * (TRAINER:58-68: lr0 * (1 - step / steps), applied AFTER the step). */
+int mtk_train_apply(mtk_ctx* ctx, double lr, double weight_decay, double beta1, double beta2, double eps,
+                    int64_t step, double ema_rate, mtk_stream stream);
+/* Copies image `image` to / from PyTorch-layout tensors (order as in mtk_mlp_set_weights): how the host
+ * reads back the trained weights / the EMA model, or restores optimizer state. */
+int mtk_train_export(mtk_ctx* ctx, int image, float* const* W, float* const* b, mtk_stream stream);
+int mtk_train_import(mtk_ctx* ctx, int image, const float* const* W, const float* const* b, mtk_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,3 +19,4 @@ from .model import (  # noqa: F401
 from .schedule import SchedulerType, betas_for_alpha_bar, get_named_beta_schedule  # noqa: F401
 from .scoring import mixed_loss as tartan_federer_mixed_loss  # noqa: F401
 from .scoring import score_records  # noqa: F401
+from .trainer import ClavaDDPMTrainer, update_ema  # noqa: F401

@@ -9,6 +9,7 @@ pids=()
 # the diffusion kernels mirror eager fp32 op sequences: no fused multiply-add contraction
 hipcc $FLAGS -ffp-contract=off -c mtk_diffusion.hip -o _build/mtk_diffusion.o & pids+=($!)
 hipcc $FLAGS -ffp-contract=off -c mtk_tf.hip -o _build/mtk_tf.o & pids+=($!)
+hipcc $FLAGS -ffp-contract=off -c mtk_train.hip -o _build/mtk_train.o & pids+=($!)
 hipcc $FLAGS -c mtk_capi.hip -o _build/mtk_capi.o & pids+=($!)
 hipcc $FLAGS -c mtk_mlp_f32.hip -o _build/mtk_mlp_f32.o & pids+=($!)
 hipcc $FLAGS -c mtk_mlp_bf16.hip -o _build/mtk_mlp_bf16.o & pids+=($!)

@@ -45,6 +45,30 @@ struct MlpLayer {
     int in_pad = 0, out_pad = 0;  // padded to the fp32 GEMM tile (K: 32, N: 128)
     float* w32 = nullptr;         // [out_pad][in_pad] fp32, zero padded
     float* b32 = nullptr;         // [out_pad]
+    bool owned = true;            // false while the layer reads from an attached training image
+};
+
+// Training state (mtk_train.hip, a19).  The five parameter images (weights, gradients, Adam m, Adam v, EMA) live in
+// ONE caller-owned buffer so the host can all-reduce the gradient image; activations are context-owned.
+struct TrainLayerRef {
+    MlpLayer* l = nullptr;
+    size_t w_off = 0, b_off = 0;  // element offsets inside one image
+};
+struct TrainState {
+    bool attached = false;
+    float* state = nullptr;  // caller-owned, 5 * n_img floats
+    size_t n_img = 0;
+    std::vector<TrainLayerRef> layers;  // proj, temb0, temb2, blocks..., head
+    // time-embedding tables kept for the backward pass, [Tpad][tpad]
+    float *sin_tab = nullptr, *z0_tab = nullptr, *e1_tab = nullptr, *demb = nullptr, *dtab = nullptr;
+    int Tpad = 0;
+    // activations for `cap` rows (a multiple of 128)
+    int64_t cap = 0;
+    float* xin = nullptr;          // [round_up(D,128)][cap] column-major model input
+    int32_t* xt_idx = nullptr;     // [C][cap]
+    std::vector<float*> act;       // act[0] = proj output, act[i] = block i output, row-major [cap][out_pad]
+    float *out = nullptr, *dout = nullptr;  // column-major [Dpad128][cap]
+    float* dact[2] = {nullptr, nullptr};   // row-major [cap][max_pad] gradient ping-pong
 };
 
 struct mtk_ctx {
@@ -78,6 +102,7 @@ struct mtk_ctx {
     // workspace of the unfused Tartan-Federer path (x_t and eps_hat, row-major [rows][Nn])
     float* tf_ws[2] = {nullptr, nullptr};
     size_t tf_ws_elems = 0;
+    TrainState train;
 
     DevTables dev() const { return DevTables{d_rows, d_off, d_logK, T, Nn, C, S}; }
     double tab(int which, int t) const { return tables[(size_t)which * T + t]; }

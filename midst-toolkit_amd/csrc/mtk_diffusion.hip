@@ -625,6 +625,137 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// loss_rows + its gradient with respect to the denoiser output (a19: the head of the backward pass).
+// Same quantities as k_loss_rows_fast (exact per-block log-sum-exp, closed-form true posterior); FAST selects
+// hardware or libm transcendentals.  Per block, with lsm = log_softmax(logits), ev = q_pred(lsm, t-1),
+// un = ev + q(x_t | .), p = softmax(un), w = true posterior:
+//   t > 0:  d KL / d un_i = p_i sum(w) - w_i        t = 0:  d NLL / d un_i = p_i - [i = x_0]
+//   d un_i / d lsm_i = s_i = exp(lsm_i + log acp_{t-1} - ev_i)  (1 at t = 0)
+//   d loss / d logit_i = g_i - softmax(logits)_i sum_j g_j,  g_i = (d loss / d un_i) s_i
+// `out` and `dout` are column-major [D][ld].
+// ------------------------------------------------------------------------------------------------
+struct LossGradArgs {
+    DevTables d;
+    int64_t B;
+    const float* out; int64_t ld;
+    const float* x0; int64_t x0_ld;
+    const int32_t* xt_idx;
+    const float* eps;
+    const int64_t* t;
+    float* loss_multi;
+    float* loss_gauss;
+    float* dout;
+    float gscale, mscale;  // 2 / (Nn B_global),  T / (C B_global)
+    uint64_t seed, row0;
+};
+
+template <bool FAST> __device__ __forceinline__ float ex(float x) { return FAST ? __expf(x) : expf(x); }
+template <bool FAST> __device__ __forceinline__ float lg(float x) { return FAST ? __logf(x) : logf(x); }
+template <bool FAST> __device__ __forceinline__ float lae_t(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m + lg<FAST>(ex<FAST>(a - m) + ex<FAST>(b - m));
+}
+
+template <bool LDS_ROWS, bool FAST>
+__global__ __launch_bounds__(kBlock) void k_loss_grad(LossGradArgs a) {
+    const Staged s = stage_tables<LDS_ROWS>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
+    const SchedRow srT = s.rows[T - 1];
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int t = (int)a.t[row];
+        const float* mo = a.out + row;
+        float* go = a.dout + row;
+        if (Nn > 0) {
+            PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
+            PhiloxNF pf(a.seed, a.row0 + row, MTK_STREAM_EPS);
+            float acc = 0.0f;
+            for (int j = 0; j < Nn; ++j) {
+                const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
+                const float df = mo[j * a.ld] - e;
+                acc += df * df;
+                go[j * a.ld] = a.gscale * df;
+            }
+            if (a.loss_gauss) a.loss_gauss[row] = acc / (float)Nn;
+        }
+        if (C == 0) continue;
+        const SchedRow st = s.rows[t];
+        const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
+        const float* xr = a.x0 + row * a.x0_ld;
+        float kl = 0.0f, nll = 0.0f, prior = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const float logK = s.logK[k];
+            const int c0 = (int)(long long)xr[Nn + k];
+            const int ct = a.xt_idx[(int64_t)k * a.B + row];
+            const float* mc = mo + (int64_t)(Nn + o) * a.ld;
+            float* gc = go + (int64_t)(Nn + o) * a.ld;
+            const float cq = st.log_1m_alpha - logK;
+            const float q_hot = lae_t<FAST>(0.0f + st.log_alpha, cq), q_cold = lae_t<FAST>(MTK_LOG_TINY + st.log_alpha, cq);
+            const float ce = s1.log_1m_acp - logK;
+            const float e_hot = (t == 0) ? 0.0f : lae_t<FAST>(0.0f + s1.log_acp, ce);
+            const float e_cold = (t == 0) ? MTK_LOG_TINY : lae_t<FAST>(MTK_LOG_TINY + s1.log_acp, ce);
+            const float v_c0 = e_hot + ((c0 == ct) ? q_hot : q_cold);
+            const float v_ct = e_cold + q_hot;
+            const float v_cc = e_cold + q_cold;
+            const int n_cc = Kk - ((c0 == ct) ? 1 : 2);
+            const float m_t = fmaxf(v_c0, fmaxf(v_ct, v_cc));
+            float b_t = ex<FAST>(v_c0 - m_t) + (float)n_cc * ex<FAST>(v_cc - m_t);
+            if (c0 != ct) b_t += ex<FAST>(v_ct - m_t);
+            const float lse_t = m_t + lg<FAST>(b_t);
+            const float lt_c0 = v_c0 - lse_t, lt_ct = v_ct - lse_t, lt_cc = v_cc - lse_t;
+            const float w_c0 = ex<FAST>(lt_c0), w_ct = ex<FAST>(lt_ct), w_cc = ex<FAST>(lt_cc);
+            const float w_sum = w_c0 + (float)n_cc * w_cc + ((c0 != ct) ? w_ct : 0.0f);
+            float mx = -INFINITY;
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.ld]);
+            float sum = 0.0f;
+            for (int i = 0; i < Kk; ++i) sum += ex<FAST>(mc[i * a.ld] - mx);
+            const float lsum = lg<FAST>(sum);
+            const float ev_top = (t == 0) ? -lsum : lae_t<FAST>(-lsum + s1.log_acp, ce);
+            const float m_m = ev_top + q_hot;
+            float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
+            for (int i = 0; i < Kk; ++i) {
+                const float lsm = (mc[i * a.ld] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
+                const float un = ev + ((i == ct) ? q_hot : q_cold);
+                b_m += ex<FAST>(un - m_m);
+                const float lt = (i == c0) ? lt_c0 : ((i == ct) ? lt_ct : lt_cc);
+                const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
+                acc_kl += w * (lt - un);
+                if (i == c0) un_c0 = un;
+            }
+            const float lse_m = m_m + lg<FAST>(b_m);
+            kl += acc_kl + lse_m * w_sum;
+            nll += un_c0 - lse_m;
+            const float cT = srT.log_1m_acp - logK;
+            const float p_hot = lae_t<FAST>(0.0f + srT.log_acp, cT), p_cold = lae_t<FAST>(MTK_LOG_TINY + srT.log_acp, cT);
+            prior += ex<FAST>(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (ex<FAST>(p_cold) * (p_cold + logK));
+            // gradient: first pass stores g_i and accumulates their sum, second pass projects through the softmax
+            float G = 0.0f;
+            for (int i = 0; i < Kk; ++i) {
+                const float lsm = (mc[i * a.ld] - mx) - lsum;
+                const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
+                const float un = ev + ((i == ct) ? q_hot : q_cold);
+                const float p = ex<FAST>(un - lse_m);
+                const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
+                const float gun = (t == 0) ? (p - ((i == c0) ? 1.0f : 0.0f)) : (p * w_sum - w);
+                const float sl = (t == 0) ? 1.0f : ex<FAST>((lsm + s1.log_acp) - ev);
+                const float gi = gun * sl;
+                G += gi;
+                gc[i * a.ld] = gi;
+            }
+            for (int i = 0; i < Kk; ++i) {
+                const float sm = ex<FAST>((mc[i * a.ld] - mx) - lsum);
+                gc[i * a.ld] = a.mscale * (gc[i * a.ld] - sm * G);
+            }
+        }
+        if (a.loss_multi) {
+            const float lt = (t == 0) ? -nll : kl;
+            a.loss_multi[row] = (lt * (float)T + prior) / (float)C;
+        }
+    }
+}
+
 int grid_for(int64_t B) {
     int64_t g = (B + kBlock - 1) / kBlock;
     if (g > 2048) g = 2048;  // 256 CUs x 8 resident workgroups; grid-stride covers the rest
@@ -638,6 +769,20 @@ size_t lds_bytes(const mtk_ctx* c, bool rows) {
 }
 
 }  // namespace
+
+// internal (mtk_train.hip): per-record losses and d(mean loss)/d(out); out / dout column-major [D][ld]
+int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
+                         const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
+                         float* dout, double inv_global_batch, uint64_t seed, uint64_t row0, hipStream_t stream) {
+    LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
+                   ctx->Nn > 0 ? (float)(2.0 * inv_global_batch / ctx->Nn) : 0.0f,
+                   ctx->C > 0 ? (float)((double)ctx->T * inv_global_batch / ctx->C) : 0.0f, seed, row0};
+    const bool lds = ctx->T <= MTK_LDS_T_MAX;
+    auto k = ctx->fast_math ? (lds ? k_loss_grad<true, true> : k_loss_grad<false, true>) : (lds ? k_loss_grad<true, false> : k_loss_grad<false, false>);
+    hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
 
 extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
                             const float* u, float* x_in, int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed,

@@ -10,6 +10,7 @@
 
 int mtk_pack_fused(mtk_ctx* c, hipStream_t s);    // mtk_mlp_bf16.hip
 void mtk_free_fused(mtk_ctx* c);                  // mtk_mlp_bf16.hip
+void mtk_free_train(mtk_ctx* c);                  // mtk_train.hip
 int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                       float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16.hip
 
@@ -149,8 +150,8 @@ __global__ void k_sinusoid(float* dst, int Tpad, int ld, int T, int dim, const f
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 void free_layer(MlpLayer& l) {
-    if (l.w32) (void)hipFree(l.w32);
-    if (l.b32) (void)hipFree(l.b32);
+    if (l.owned && l.w32) (void)hipFree(l.w32);
+    if (l.owned && l.b32) (void)hipFree(l.b32);
     l = MlpLayer();
 }
 
@@ -197,6 +198,7 @@ void mtk_free_mlp(mtk_ctx* c) {
     }
     c->tf_ws_elems = 0;
     mtk_free_fused(c);
+    mtk_free_train(c);
     c->have_weights = false;
 }
 

@@ -1,0 +1,580 @@
+// mtk_train.hip — one training iteration of the denoiser on gfx950.
+//
+// Reference: models/clavaddpm/trainer.py:70-94 (zero_grad, mixed_loss, backward, AdamW.step),
+// :58-68 (learning-rate anneal, applied after the step) and :138-155 (EMA of the denoiser).
+//
+// Layout.  The five parameter images (weights, gradients, Adam m, Adam v, EMA) have the padded layout the
+// forward GEMMs already use ([out_pad][in_pad] + [out_pad] per Linear, zero padding) and sit back to back in ONE
+// caller-owned buffer: the host all-reduces the gradient image over RCCL between mtk_train_step and
+// mtk_train_apply, and padding entries stay exactly zero under AdamW (zero gradient, zero weight).
+//
+// Kernels.  One fp32 GEMM kernel on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate), 128x128x32
+// workgroup tile, with either operand read row-major or transposed and three epilogues: forward
+// (bias [+ time embedding] [+ ReLU]), dgrad (ReLU mask of the saved activation) and wgrad (split-K over the batch,
+// hardware fp32 atomic add into the zeroed gradient image).  The loss and its gradient come from
+// k_loss_grad (mtk_diffusion.hip); AdamW + EMA is one elementwise pass over the image.
+#include <math.h>
+
+#include "mtk_common.h"
+
+int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
+                         const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
+                         float* dout, double inv_global_batch, uint64_t seed, uint64_t row0, hipStream_t stream);  // mtk_diffusion.hip
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TM = 128, TN = 128, TK = 32;
+constexpr int LDN = TK + 4;    // row-major tile in LDS: [128][36]
+constexpr int LDT = TM + 4;    // transposed tile in LDS: [32][132]
+constexpr int TILE_FLOATS = TM * LDN > TK * LDT ? TM * LDN : TK * LDT;
+
+struct G2 {
+    int M, N, K;            // M and K are tile multiples; N is the number of columns stored (grid.y covers it)
+    int kchunk;             // reduction range per blockIdx.z (multiple of 32)
+    const float* A; int64_t lda;   // AT ? A[k * lda + m] : A[m * lda + k]
+    const float* B; int64_t ldb;   // BT ? B[k * ldb + n] : B[n * ldb + k]
+    float* C; int64_t c_rs, c_cs;  // C[m * c_rs + n * c_cs]
+    const float* bias;             // [grid.y * 128] or null
+    const float* emb; int emb_ld;  // optional [T][emb_ld], gathered by tvec[m]
+    const int64_t* tvec; int64_t rows_valid;
+    const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed where mask <= 0
+    int relu;
+    int atomic;                    // accumulate with fp32 atomic add (split-K)
+};
+
+template <bool TR>
+__device__ __forceinline__ void load_tile(float* lds, const float* src, int64_t ld, int64_t r0, int k0, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q;
+        if (!TR) {
+            const int r = idx >> 3, c = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(&lds[r * LDN + c]) = *reinterpret_cast<const float4*>(src + (r0 + r) * ld + k0 + c);
+        } else {
+            const int kk = idx >> 5, r4 = (idx & 31) * 4;
+            *reinterpret_cast<float4*>(&lds[kk * LDT + r4]) = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + kk) * ld + r0 + r4);
+        }
+    }
+}
+// lane (li, hh) takes k in [16 hh, 16 hh + 16) of the K block for both operands
+template <bool TR>
+__device__ __forceinline__ void fetch_frag(const float* lds, int row, int hh, float (&f)[16]) {
+    if (!TR) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(&lds[row * LDN + 16 * hh + 4 * q]);
+            f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) f[s] = lds[(16 * hh + s) * LDT + row];
+    }
+}
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void k_gemm2(G2 g) {
+    __shared__ __attribute__((aligned(16))) float As[TILE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[TILE_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int n0 = blockIdx.y * TN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        load_tile<AT>(As, g.A, g.lda, m0, k0, tid);
+        load_tile<BT>(Bs, g.B, g.ldb, n0, k0, tid);
+        __syncthreads();
+        float a[2][16], b[2][16];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) fetch_frag<AT>(As, wr * 64 + mt * 32 + li, hh, a[mt]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) fetch_frag<BT>(Bs, wc * 64 + nt * 32 + li, hh, b[nt]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wc * 64 + nt * 32 + li;
+            if (n >= g.N) continue;
+            const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[mt][nt][r] + bias;
+                if (g.emb) {
+                    const int tr = (row < g.rows_valid) ? (int)g.tvec[row] : 0;
+                    v += g.emb[(int64_t)tr * g.emb_ld + n];
+                }
+                if (g.relu) v = fmaxf(v, 0.0f);
+                if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v : 0.0f;
+                float* dst = g.C + row * g.c_rs + (int64_t)n * g.c_cs;
+                if (g.atomic) unsafeAtomicAdd(dst, v); else *dst = v;
+            }
+        }
+}
+
+template <bool AT, bool BT>
+int launch(const G2& g, hipStream_t s) {
+    const int splits = (g.K + g.kchunk - 1) / g.kchunk;
+    hipLaunchKernelGGL((k_gemm2<AT, BT>), dim3((unsigned)(g.M / TM), (unsigned)((g.N + TN - 1) / TN), (unsigned)splits), dim3(256), 0, s, g);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+// bias gradient of a row-major dY [rows][ld]: column sums, rows split over blockIdx.y, atomic accumulate
+__global__ __launch_bounds__(256) void k_colsum_rm(const float* dy, int64_t ld, int64_t rows, int n, float* db) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float acc = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) acc += dy[r * ld + c];
+    unsafeAtomicAdd(&db[c], acc);
+}
+// bias gradient of a column-major dY [n][ld]: one workgroup per feature
+__global__ __launch_bounds__(256) void k_rowsum_cm(const float* dy, int64_t ld, int64_t rows, float* db) {
+    __shared__ float part[256];
+    const float* src = dy + (int64_t)blockIdx.x * ld;
+    float acc = 0.0f;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) acc += src[r];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[blockIdx.x] = part[0];
+}
+// d emb[t[row]][:] += d act0[row][:]   (the time embedding is added to the proj output, MODEL:608-611)
+__global__ __launch_bounds__(256) void k_scatter_emb(const float* dact, int64_t ld, const int64_t* t, int64_t rows, int n, float* demb, int emb_ld) {
+    const int64_t total = rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n;
+        const int c = (int)(i % n);
+        unsafeAtomicAdd(&demb[t[r] * emb_ld + c], dact[r * ld + c]);
+    }
+}
+__global__ void k_silu(const float* z, float* y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = z[i];
+        y[i] = v / (1.0f + expf(-v));
+    }
+}
+// dz = dy * silu'(z),  silu'(z) = sig (1 + z (1 - sig))
+__global__ void k_silu_bwd(const float* z, float* dy, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = z[i], sg = 1.0f / (1.0f + expf(-v));
+        dy[i] *= sg * (1.0f + v * (1.0f - sg));
+    }
+}
+// MODEL:123-144 sinusoid table (same expression as k_sinusoid of mtk_mlp_f32.hip)
+__global__ void k_sin_tab(float* dst, int Tpad, int ld, int T, int dim, const float* freqs) {
+    const int half = dim / 2;
+    const int64_t n = (int64_t)Tpad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / ld), c = (int)(i % ld);
+        float v = 0.0f;
+        if (t < T && c < 2 * half) {
+            const float arg = (float)t * freqs[c < half ? c : c - half];
+            v = c < half ? cosf(arg) : sinf(arg);
+        }
+        dst[i] = v;
+    }
+}
+
+// torch.optim.AdamW (single-tensor path) followed by the EMA of TRAINER:138-155, one pass over the image.
+struct AdamArgs {
+    float *p, *m, *v, *ema;
+    const float* g;
+    int64_t n;
+    float decay;        // 1 - lr * weight_decay
+    float beta1_c;      // 1 - beta1
+    float beta2, beta2_c;
+    float step_size;    // lr / (1 - beta1^step)
+    float bc2_sqrt;     // sqrt(1 - beta2^step)
+    float eps, ema_rate, ema_c;
+};
+__global__ __launch_bounds__(256) void k_adamw_ema(AdamArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        const float g = a.g[i];
+        float p = a.p[i] * a.decay;
+        float m = a.m[i];
+        m = m + a.beta1_c * (g - m);                 // exp_avg.lerp_(grad, 1 - beta1)
+        const float v = a.v[i] * a.beta2 + a.beta2_c * g * g;
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        p = p - a.step_size * (m / denom);
+        a.p[i] = p;
+        a.m[i] = m;
+        a.v[i] = v;
+        a.ema[i] = a.ema[i] * a.ema_rate + a.ema_c * p;
+    }
+}
+
+// image <-> caller tensors (unpadded [out][in] / [out])
+__global__ void k_unpad(const float* src, int ld, float* dst, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[(i / cols) * ld + (i % cols)];
+}
+__global__ void k_pad(float* dst, int ld, const float* src, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[(i / cols) * ld + (i % cols)] = src[i];
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
+    std::vector<MlpLayer*> v{&c->proj, &c->temb0, &c->temb2};
+    for (auto& l : c->blocks) v.push_back(&l);
+    v.push_back(&c->head);
+    return v;
+}
+
+void free_acts(TrainState& tr) {
+    auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(tr.xin); fr(tr.xt_idx); fr(tr.out); fr(tr.dout); fr(tr.dact[0]); fr(tr.dact[1]);
+    for (auto& p : tr.act) fr(p);
+    tr.act.clear();
+    tr.cap = 0;
+}
+
+int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
+    TrainState& tr = c->train;
+    if (Mpad <= tr.cap) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    free_acts(tr);
+    const int Dp = round_up(c->D, 128);
+    int maxpad = c->proj.out_pad;
+    for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
+    MTK_HIP(hipMalloc(&tr.xin, sizeof(float) * (size_t)Dp * Mpad));
+    MTK_HIP(hipMalloc(&tr.xt_idx, sizeof(int32_t) * (size_t)(c->C > 0 ? c->C : 1) * Mpad));
+    MTK_HIP(hipMalloc(&tr.out, sizeof(float) * (size_t)Dp * Mpad));
+    MTK_HIP(hipMalloc(&tr.dout, sizeof(float) * (size_t)Dp * Mpad));
+    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact[i], sizeof(float) * (size_t)Mpad * maxpad));
+    tr.act.assign(1 + c->blocks.size(), nullptr);
+    MTK_HIP(hipMalloc(&tr.act[0], sizeof(float) * (size_t)Mpad * c->proj.out_pad));
+    for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act[1 + i], sizeof(float) * (size_t)Mpad * c->blocks[i].out_pad));
+    tr.cap = Mpad;
+    return MTK_OK;
+}
+
+// emb[t] = Linear2(SiLU(Linear0(sinusoid(t)))) from the CURRENT weights, keeping the intermediates
+int refresh_emb(mtk_ctx* c, hipStream_t s) {
+    TrainState& tr = c->train;
+    const int tp = c->emb_ld;
+    int rc;
+    G2 g{};
+    g.M = tr.Tpad; g.N = tp; g.K = tp; g.kchunk = tp;
+    g.A = tr.sin_tab; g.lda = tp; g.B = c->temb0.w32; g.ldb = tp; g.C = tr.z0_tab; g.c_rs = tp; g.c_cs = 1; g.bias = c->temb0.b32;
+    if ((rc = launch<false, false>(g, s))) return rc;
+    hipLaunchKernelGGL(k_silu, dim3(256), dim3(256), 0, s, tr.z0_tab, tr.e1_tab, (int64_t)tr.Tpad * tp);
+    g.A = tr.e1_tab; g.B = c->temb2.w32; g.C = c->d_emb; g.bias = c->temb2.b32;
+    if ((rc = launch<false, false>(g, s))) return rc;
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+int kchunk_for(int64_t K, int tiles) {
+    // enough workgroups for 256 CUs: tiles * splits >= ~512, chunks of at least 256 reduction steps
+    int64_t splits = (512 + tiles - 1) / tiles;
+    int64_t ch = (K + splits - 1) / splits;
+    if (ch < 256) ch = 256;
+    ch = (ch + TK - 1) / TK * TK;
+    return (int)(ch > K ? K : ch);
+}
+
+}  // namespace
+
+void mtk_free_train(mtk_ctx* c) {
+    TrainState& tr = c->train;
+    auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(tr.sin_tab); fr(tr.z0_tab); fr(tr.e1_tab); fr(tr.demb); fr(tr.dtab);
+    free_acts(tr);
+    tr.layers.clear();
+    tr.attached = false;
+    tr.state = nullptr;
+    tr.n_img = 0;
+}
+
+extern "C" int64_t mtk_train_image_elems(mtk_ctx* c) {
+    if (!c || !c->have_weights) return 0;
+    int64_t n = 0;
+    for (MlpLayer* l : layer_list(c)) n += (int64_t)l->out_pad * l->in_pad + l->out_pad;
+    return n;
+}
+
+extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_host, mtk_stream stream) {
+    if (!c || !state || !freqs_host) MTK_FAIL(MTK_ERR_ARG, "mtk_train_attach: null argument");
+    if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_train_attach: call mtk_mlp_set_weights first");
+    if (c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_attach: a training image is already attached (set the weights again to detach)");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    MTK_HIP(hipStreamSynchronize(s));
+    TrainState& tr = c->train;
+    const size_t n = (size_t)mtk_train_image_elems(c);
+    tr.layers.clear();
+    size_t off = 0;
+    for (MlpLayer* l : layer_list(c)) {
+        TrainLayerRef r;
+        r.l = l;
+        r.w_off = off;
+        off += (size_t)l->out_pad * l->in_pad;
+        r.b_off = off;
+        off += (size_t)l->out_pad;
+        tr.layers.push_back(r);
+    }
+    // image 0 <- current weights; image 4 (EMA) <- the same; gradients, m, v <- 0
+    for (auto& r : tr.layers) {
+        MTK_HIP(hipMemcpyAsync(state + r.w_off, r.l->w32, sizeof(float) * (size_t)r.l->out_pad * r.l->in_pad, hipMemcpyDeviceToDevice, s));
+        MTK_HIP(hipMemcpyAsync(state + r.b_off, r.l->b32, sizeof(float) * (size_t)r.l->out_pad, hipMemcpyDeviceToDevice, s));
+    }
+    MTK_HIP(hipMemsetAsync(state + n, 0, sizeof(float) * 3 * n, s));
+    MTK_HIP(hipMemcpyAsync(state + 4 * n, state, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    MTK_HIP(hipStreamSynchronize(s));
+    for (auto& r : tr.layers) {
+        if (r.l->owned) {
+            (void)hipFree(r.l->w32);
+            (void)hipFree(r.l->b32);
+        }
+        r.l->w32 = state + r.w_off;
+        r.l->b32 = state + r.b_off;
+        r.l->owned = false;
+    }
+    tr.state = state;
+    tr.n_img = n;
+    // time-embedding intermediates
+    const int tp = c->emb_ld;
+    tr.Tpad = round_up(c->T, TM);
+    const size_t tb = sizeof(float) * (size_t)tr.Tpad * tp;
+    MTK_HIP(hipMalloc(&tr.sin_tab, tb));
+    MTK_HIP(hipMalloc(&tr.z0_tab, tb));
+    MTK_HIP(hipMalloc(&tr.e1_tab, tb));
+    MTK_HIP(hipMalloc(&tr.demb, tb));
+    MTK_HIP(hipMalloc(&tr.dtab, tb));
+    float* d_freq = nullptr;
+    MTK_HIP(hipMalloc(&d_freq, sizeof(float) * (c->dim_t / 2)));
+    MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (c->dim_t / 2), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sin_tab, dim3(256), dim3(256), 0, s, tr.sin_tab, tr.Tpad, tp, c->T, c->dim_t, d_freq);
+    int rc = refresh_emb(c, s);
+    MTK_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_freq);
+    if (rc) return rc;
+    c->fused_ok = false;  // the packed bf16 image no longer tracks the weights
+    tr.attached = true;
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                              const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
+                              uint64_t row0, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null context");
+    if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_step: call mtk_train_attach first");
+    if (B <= 0 || !x0 || !t) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null pointer or B <= 0");
+    if (B > (1 << 22)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_step: B = %lld above 4194304 rows per call", (long long)B);
+    if (x0_ld < c->Nn + c->C) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: x0_ld too small");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    TrainState& tr = c->train;
+    const int64_t Mpad = (B + TM - 1) / TM * TM;
+    int rc;
+    if ((rc = ensure_acts(c, Mpad, s))) return rc;
+    const int64_t ld = tr.cap;  // leading dimension of the column-major buffers
+    const int Dp = round_up(c->D, 128);
+    const size_t n = tr.n_img;
+    float* grads = tr.state + n;
+
+    MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
+    MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * ld, s));
+    MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
+    MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
+
+    // ---- forward, activations kept
+    // xt_idx is addressed [C][B] by the kernels (row stride B)
+    if ((rc = mtk_q_sample(c, B, x0, x0_ld, t, eps, u, tr.xin, 1, ld, tr.xt_idx, seed, row0, stream))) return rc;
+    {
+        G2 g{};
+        g.M = (int)Mpad; g.N = c->proj.out_pad; g.K = c->proj.in_pad; g.kchunk = g.K;
+        g.A = tr.xin; g.lda = ld; g.B = c->proj.w32; g.ldb = c->proj.in_pad;
+        g.C = tr.act[0]; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
+        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t; g.rows_valid = B;
+        if ((rc = launch<true, false>(g, s))) return rc;
+    }
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+        MlpLayer& l = c->blocks[i];
+        G2 g{};
+        g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
+        g.A = tr.act[i]; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
+        g.C = tr.act[i + 1]; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32; g.relu = 1;
+        if ((rc = launch<false, false>(g, s))) return rc;
+    }
+    {
+        MlpLayer& l = c->head;
+        G2 g{};
+        g.M = (int)Mpad; g.N = l.out; g.K = l.in_pad; g.kchunk = g.K;
+        g.A = tr.act.back(); g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
+        g.C = tr.out; g.c_rs = 1; g.c_cs = ld; g.bias = l.b32;
+        if ((rc = launch<false, false>(g, s))) return rc;
+    }
+    // ---- loss and d loss / d out (column-major, rows >= B and features >= D stay zero)
+    if ((rc = mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout,
+                                   inv_global_batch, seed, row0, s)))
+        return rc;
+
+    // ---- backward
+    auto ref_of = [&](MlpLayer* l) -> TrainLayerRef& {
+        for (auto& r : tr.layers) if (r.l == l) return r;
+        return tr.layers[0];
+    };
+    {   // head: dW[o][k] = sum_m dout[o][m] act[m][k];  db = row sums;  d act = dout^T W  masked by act > 0
+        MlpLayer& l = c->head;
+        TrainLayerRef& r = ref_of(&l);
+        G2 g{};
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
+        g.A = tr.dout; g.lda = ld; g.B = tr.act.back(); g.ldb = l.in_pad;
+        g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
+        if ((rc = launch<false, true>(g, s))) return rc;
+        hipLaunchKernelGGL(k_rowsum_cm, dim3(l.out), dim3(256), 0, s, tr.dout, ld, Mpad, grads + r.b_off);
+        G2 d{};
+        d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
+        d.A = tr.dout; d.lda = ld; d.B = l.w32; d.ldb = l.in_pad;
+        d.C = tr.dact[0]; d.c_rs = l.in_pad; d.c_cs = 1;
+        if (!c->blocks.empty()) { d.mask = tr.act.back(); d.m_rs = l.in_pad; }
+        if ((rc = launch<true, true>(d, s))) return rc;
+    }
+    int cur = 0;
+    for (int i = (int)c->blocks.size() - 1; i >= 0; --i) {
+        MlpLayer& l = c->blocks[i];
+        TrainLayerRef& r = ref_of(&l);
+        const float* dy = tr.dact[cur];  // [Mpad][out_pad], already masked by this layer's ReLU
+        G2 g{};
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
+        g.A = dy; g.lda = l.out_pad; g.B = tr.act[i]; g.ldb = l.in_pad;
+        g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
+        if ((rc = launch<true, true>(g, s))) return rc;
+        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 64), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
+        G2 d{};
+        d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
+        d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
+        d.C = tr.dact[cur ^ 1]; d.c_rs = l.in_pad; d.c_cs = 1;
+        if (i > 0) { d.mask = tr.act[i]; d.m_rs = l.in_pad; }  // act[0] (proj + emb) has no ReLU
+        if ((rc = launch<false, true>(d, s))) return rc;
+        cur ^= 1;
+    }
+    {   // proj: dW[o][k] = sum_m dact0[m][o] xin[k][m];  db;  d emb table
+        MlpLayer& l = c->proj;
+        TrainLayerRef& r = ref_of(&l);
+        const float* dy = tr.dact[cur];  // [Mpad][proj.out_pad]
+        G2 g{};
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
+        g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
+        g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
+        if ((rc = launch<true, false>(g, s))) return rc;
+        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 64), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
+        hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(256), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld);
+    }
+    {   // time-embedding MLP over the T-row table
+        const int tp = c->emb_ld;
+        MlpLayer &l2 = c->temb2, &l0 = c->temb0;
+        TrainLayerRef &r2 = ref_of(&l2), &r0 = ref_of(&l0);
+        G2 g{};
+        g.M = tp; g.N = tp; g.K = tr.Tpad; g.kchunk = kchunk_for(tr.Tpad, (tp / TM) * (tp / TN));
+        g.A = tr.demb; g.lda = tp; g.B = tr.e1_tab; g.ldb = tp; g.C = grads + r2.w_off; g.c_rs = tp; g.c_cs = 1; g.atomic = 1;
+        if ((rc = launch<true, true>(g, s))) return rc;
+        hipLaunchKernelGGL(k_colsum_rm, dim3((tp + 255) / 256, 16), dim3(256), 0, s, tr.demb, (int64_t)tp, (int64_t)tr.Tpad, tp, grads + r2.b_off);
+        G2 d{};
+        d.M = tr.Tpad; d.N = tp; d.K = tp; d.kchunk = tp;
+        d.A = tr.demb; d.lda = tp; d.B = l2.w32; d.ldb = tp; d.C = tr.dtab; d.c_rs = tp; d.c_cs = 1;
+        if ((rc = launch<false, true>(d, s))) return rc;
+        hipLaunchKernelGGL(k_silu_bwd, dim3(256), dim3(256), 0, s, tr.z0_tab, tr.dtab, (int64_t)tr.Tpad * tp);
+        g.A = tr.dtab; g.B = tr.sin_tab; g.C = grads + r0.w_off;
+        if ((rc = launch<true, true>(g, s))) return rc;
+        hipLaunchKernelGGL(k_colsum_rm, dim3((tp + 255) / 256, 16), dim3(256), 0, s, tr.dtab, (int64_t)tp, (int64_t)tr.Tpad, tp, grads + r0.b_off);
+    }
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, double beta1, double beta2, double eps,
+                               int64_t step, double ema_rate, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_apply: null context");
+    if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_apply: call mtk_train_attach first");
+    if (step < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_train_apply: step is 1-based");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    TrainState& tr = c->train;
+    const size_t n = tr.n_img;
+    AdamArgs a;
+    a.p = tr.state; a.g = tr.state + n; a.m = tr.state + 2 * n; a.v = tr.state + 3 * n; a.ema = tr.state + 4 * n;
+    a.n = (int64_t)n;
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.beta1_c = (float)(1.0 - beta1);
+    a.beta2 = (float)beta2;
+    a.beta2_c = (float)(1.0 - beta2);
+    a.step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    a.eps = (float)eps;
+    a.ema_rate = (float)ema_rate;
+    a.ema_c = (float)(1.0 - ema_rate);
+    hipLaunchKernelGGL(k_adamw_ema, dim3(1024), dim3(256), 0, s, a);
+    MTK_HIP(hipGetLastError());
+    return refresh_emb(c, s);
+}
+
+extern "C" int mtk_train_export(mtk_ctx* c, int image, float* const* W, float* const* b, mtk_stream stream) {
+    if (!c || !W || !b) MTK_FAIL(MTK_ERR_ARG, "mtk_train_export: null argument");
+    if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_export: no training image attached");
+    if (image < 0 || image > 4) MTK_FAIL(MTK_ERR_ARG, "mtk_train_export: image %d outside [0, 4]", image);
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    TrainState& tr = c->train;
+    const float* img = tr.state + (size_t)image * tr.n_img;
+    for (size_t i = 0; i < tr.layers.size(); ++i) {
+        const MlpLayer& l = *tr.layers[i].l;
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_train_export: W[%zu] or b[%zu] is null", i, i);
+        hipLaunchKernelGGL(k_unpad, dim3(256), dim3(256), 0, s, img + tr.layers[i].w_off, l.in_pad, W[i], l.out, l.in);
+        hipLaunchKernelGGL(k_unpad, dim3(4), dim3(256), 0, s, img + tr.layers[i].b_off, l.out_pad, b[i], 1, l.out);
+    }
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_import(mtk_ctx* c, int image, const float* const* W, const float* const* b, mtk_stream stream) {
+    if (!c || !W || !b) MTK_FAIL(MTK_ERR_ARG, "mtk_train_import: null argument");
+    if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_import: no training image attached");
+    if (image < 0 || image > 4) MTK_FAIL(MTK_ERR_ARG, "mtk_train_import: image %d outside [0, 4]", image);
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    TrainState& tr = c->train;
+    float* img = tr.state + (size_t)image * tr.n_img;
+    for (size_t i = 0; i < tr.layers.size(); ++i) {
+        const MlpLayer& l = *tr.layers[i].l;
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_train_import: W[%zu] or b[%zu] is null", i, i);
+        hipLaunchKernelGGL(k_pad, dim3(256), dim3(256), 0, s, img + tr.layers[i].w_off, l.in_pad, W[i], l.out, l.in);
+        hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, img + tr.layers[i].b_off, l.out_pad, b[i], 1, l.out);
+    }
+    MTK_HIP(hipGetLastError());
+    if (image == 0) return refresh_emb(c, s);
+    return MTK_OK;
+}

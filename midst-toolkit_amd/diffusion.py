@@ -167,7 +167,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         cache = self.__dict__.setdefault("_aux", {})
         dev = self.alphas.device
         key = (n, str(dev))
-        if key not in cache:
+        if cache.get(key) is None:
             cache[key] = Engine(dev, self.num_timesteps, n, [0], self._host_tables)
         return cache[key]
 
@@ -222,8 +222,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         and ignored like the reference's denoiser ignores it (MODEL:610)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
-                "mixed_loss with autograd: the HIP backward (SURVEY section 8 row a19) is not built yet; "
-                "call under torch.no_grad() for loss evaluation / scoring"
+                "mixed_loss does not build an autograd graph: train with midst_toolkit_amd.trainer.ClavaDDPMTrainer "
+                "(HIP forward + backward + AdamW), or call under torch.no_grad() for loss evaluation / scoring"
             )
         lm, lg = self.mixed_loss_rows(features)
         return lm.mean(), lg.mean()

@@ -48,6 +48,11 @@ class Engine:
             except Exception:
                 pass
 
+    def __deepcopy__(self, memo):
+        """A device context is not copied with the module that holds it (deepcopy of a denoiser / diffusion
+        object, TRAINER:40): the copy builds its own lazily."""
+        return None
+
     def set_math(self, mode: str) -> None:
         """"reference" (parity, default) or "fast" (hardware transcendentals, exact block log-sum-exp)."""
         check(_lib.lib().mtk_ctx_set_math(self._h, {"reference": 0, "fast": 1}[mode]))
@@ -69,6 +74,7 @@ class Engine:
         f = np.ascontiguousarray(freqs.detach().cpu().numpy().astype(np.float32))
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_mlp_set_weights(self._h, n_hidden, d.ctypes.data, Wp, bp, f.ctypes.data, self._stream()))
+        self._train_state = None  # setting weights detaches a training image
 
     def mlp_forward(self, x: torch.Tensor, t, out: torch.Tensor | None = None, precision: str = "fp32",
                     x_strides=None, out_strides=None, B: int | None = None) -> torch.Tensor:
@@ -132,3 +138,46 @@ class Engine:
     def sample_decode(self, B, z, z_idx, out):
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_sample_decode(self._h, B, ptr(z), ptr(z_idx), ptr(out), self._stream()))
+
+    # ------------------------------------------------------------------ training (a19)
+    IMAGES = {"weights": 0, "grads": 1, "exp_avg": 2, "exp_avg_sq": 3, "ema": 4}
+
+    def train_attach(self, freqs: torch.Tensor) -> torch.Tensor:
+        """Allocate the [5, n] training state (weights, grads, Adam m, Adam v, EMA) and attach it."""
+        n = int(_lib.lib().mtk_train_image_elems(self._h))
+        if n <= 0:
+            raise RuntimeError("train_attach: set the denoiser weights first")
+        state = torch.empty((5, n), dtype=torch.float32, device=self.device)
+        f = np.ascontiguousarray(freqs.detach().cpu().numpy().astype(np.float32))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_attach(self._h, ptr(state), f.ctypes.data, self._stream()))
+        self._train_state = state  # keeps the buffer alive while the context reads weights from it
+        return state
+
+    def train_step(self, x0, t, eps, u, inv_global_batch, loss_multi=None, loss_gauss=None, seed=0, row0=0) -> None:
+        B = x0.shape[0]
+        assert x0.dtype == torch.float32 and x0.stride(1) == 1 and t.dtype == torch.int64 and t.is_contiguous()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_step(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), float(inv_global_batch),
+                                            ptr(loss_multi), ptr(loss_gauss), seed, row0, self._stream()))
+
+    def train_apply(self, lr, weight_decay, step, betas=(0.9, 0.999), eps=1e-8, ema_rate=0.999) -> None:
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_apply(self._h, float(lr), float(weight_decay), float(betas[0]), float(betas[1]), float(eps),
+                                             int(step), float(ema_rate), self._stream()))
+
+    def _image_io(self, fn, image, tensors):
+        Wp = (C.c_void_p * len(tensors))(*[W.data_ptr() for W, _ in tensors])
+        bp = (C.c_void_p * len(tensors))(*[b.data_ptr() for _, b in tensors])
+        with torch.cuda.device(self.device):
+            check(fn(self._h, self.IMAGES[image] if isinstance(image, str) else int(image), Wp, bp, self._stream()))
+
+    def train_export(self, image, tensors) -> None:
+        """tensors: [(W, b)] contiguous fp32 device tensors in set_weights order, overwritten in place."""
+        for W, b in tensors:
+            assert W.is_cuda and W.is_contiguous() and b.is_contiguous() and W.dtype == torch.float32
+        self._image_io(_lib.lib().mtk_train_export, image, tensors)
+
+    def train_import(self, image, tensors) -> None:
+        keep = [(W.detach().float().contiguous(), b.detach().float().contiguous()) for W, b in tensors]
+        self._image_io(_lib.lib().mtk_train_import, image, keep)

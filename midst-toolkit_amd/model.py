@@ -165,8 +165,8 @@ class MLPDiffusion(nn.Module):
             raise RuntimeError("MLPDiffusion.forward: midst_toolkit_amd has no CPU path; move the module and inputs to the MI355X")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
-                "MLPDiffusion.forward with autograd: the HIP backward (SURVEY section 8 row a19) is not built yet; "
-                "call under torch.no_grad() for scoring / sampling"
+                "MLPDiffusion.forward does not build an autograd graph: train with midst_toolkit_amd.trainer.ClavaDDPMTrainer "
+                "(HIP forward + backward + AdamW), or call under torch.no_grad() for scoring / sampling"
             )
         eng = self.engine(input_tensor.device)
         x = input_tensor.float()

@@ -1,0 +1,153 @@
+"""Drop-in for the reference's ``ClavaDDPMTrainer`` (models/clavaddpm/trainer.py:17-155).
+
+Same constructor, attributes (``loss_history``, ``ema_model``, ``log_every`` ...) and ``train()`` loop.  One
+iteration = ``mtk_train_step`` (noising -> denoiser forward -> loss -> backward, all HIP) [+ one RCCL all-reduce of
+the gradient image when ``torch.distributed`` is initialised] + ``mtk_train_apply`` (AdamW + EMA).  The weights,
+gradients, Adam moments and the EMA live in one ``[5, n]`` device tensor (``self.state``); the ``nn.Parameter``
+tensors of the denoiser (and of ``ema_model``) are refreshed from it when ``train()`` returns or on
+:meth:`sync_modules`.
+"""
+from __future__ import annotations
+
+from collections.abc import Iterator
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from .diffusion import GaussianMultinomialDiffusion
+from .model import timestep_frequencies
+
+
+class _AdamWState:
+    """Holds what the reference reads/writes on ``torch.optim.AdamW``: ``param_groups[0]['lr']`` (TRAINER:67)."""
+
+    def __init__(self, lr: float, weight_decay: float):
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": (0.9, 0.999), "eps": 1e-8}]
+        self.steps_done = 0
+
+    def zero_grad(self) -> None:  # the gradient image is zeroed inside mtk_train_step
+        pass
+
+
+class ClavaDDPMTrainer:
+    def __init__(self, diffusion_model: GaussianMultinomialDiffusion, trainer_iterator: Iterator[list[Tensor]],
+                 learning_rate: float, weight_decay: float, steps: int, device: torch.device | None = None):
+        import pandas as pd
+
+        self.diffusion_model = diffusion_model
+        self.ema_model = deepcopy(self.diffusion_model._denoise_fn)  # TRAINER:40-42
+        self.ema_model._engine, self.ema_model._synced_key, self.ema_model._engine_shared = None, None, False
+        for param in self.ema_model.parameters():
+            param.detach_()
+        self.trainer_iterator = trainer_iterator
+        self.steps = steps
+        self.initial_learning_rate = learning_rate
+        self.optimizer = _AdamWState(learning_rate, weight_decay)
+        self.device = torch.device(device) if device is not None else diffusion_model.alphas.device
+        self.loss_history = pd.DataFrame(columns=["step", "mloss", "gloss", "loss"])
+        self.log_every = 100
+        self.print_every = 500
+        self.ema_every = 1000
+        self.ema_rate = 0.999
+        self.seed = 0  # base seed of the in-kernel noise when diffusion_model.rng == "philox"
+
+        net = diffusion_model._denoise_fn
+        if getattr(net, "precision", "fp32") != "fp32" or diffusion_model.precision != "fp32":
+            raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
+        self._engine = diffusion_model.engine()
+        self.state = self._engine.train_attach(timestep_frequencies(net.timestep_dimension))
+        dist = torch.distributed
+        self._world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._rank = dist.get_rank() if self._world > 1 else 0
+
+    # ------------------------------------------------------------------ TRAINER:58
+    def _anneal_learning_rate(self, step: int) -> None:
+        frac_done = step / self.steps
+        lr = self.initial_learning_rate * (1 - frac_done)
+        for param_group in self.optimizer.param_groups:
+            param_group["lr"] = lr
+
+    # ------------------------------------------------------------------ TRAINER:70
+    def _train_step(self, input_tensor: Tensor, target: Tensor | None = None, injected=None) -> tuple[Tensor, Tensor]:
+        """``injected = (t, eps, u)`` replays given draws (parity tests); otherwise they are drawn per
+        ``diffusion_model.rng`` in the reference's order."""
+        d, eng = self.diffusion_model, self._engine
+        x0 = input_tensor.to(self.device).float().contiguous()
+        B = x0.shape[0]
+        seed = 0
+        if injected is not None:
+            t, eps, u = injected
+        elif d.rng == "torch":
+            t, eps, u = d._draw_loss_noise(x0)
+        else:
+            t = torch.randint(0, d.num_timesteps, (B,), device=x0.device).long()
+            eps = u = None
+            seed = (self.seed + 0x9E3779B97F4A7C15 * (self.optimizer.steps_done + 1)) % (1 << 63)
+        eng.set_math(d.math or ("fast" if (d.rng == "philox" and injected is None) else "reference"))
+        t = t.to(x0.device, torch.int64).contiguous()
+        eps = eps.float().contiguous() if eps is not None and eps.numel() else None
+        u = u.float().contiguous() if u is not None and u.numel() else None
+        lm = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None
+        lg = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None
+        eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
+        if self._world > 1:
+            torch.distributed.all_reduce(self.state[1])  # the one exchange of an iteration
+        g = self.optimizer.param_groups[0]
+        self.optimizer.steps_done += 1
+        eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
+        zero = torch.zeros((), dtype=torch.float32, device=x0.device)
+        return (lm.mean() if lm is not None else zero), (lg.mean() if lg is not None else zero)
+
+    # ------------------------------------------------------------------ TRAINER:96
+    def train(self) -> None:
+        step = 0
+        dev = self.device
+        curr_loss_multi = torch.zeros((), dtype=torch.float64, device=dev)
+        curr_loss_gauss = torch.zeros((), dtype=torch.float64, device=dev)
+        curr_count = 0
+        while step < self.steps:
+            input_tensor, output = next(self.trainer_iterator)
+            batch_loss_multi, batch_loss_gauss = self._train_step(input_tensor, output)
+            self._anneal_learning_rate(step)
+            n = len(input_tensor)
+            curr_count += n
+            curr_loss_multi += batch_loss_multi.double() * n  # stays on the device: no per-step sync
+            curr_loss_gauss += batch_loss_gauss.double() * n
+            if (step + 1) % self.log_every == 0:
+                mloss = np.around(curr_loss_multi.item() / curr_count, 4)
+                gloss = np.around(curr_loss_gauss.item() / curr_count, 4)
+                if (step + 1) % self.print_every == 0:
+                    print(f"Step {step + 1}/{self.steps} MLoss: {mloss} GLoss: {gloss} Sum: {mloss + gloss}", flush=True)
+                self.loss_history.loc[len(self.loss_history)] = [step + 1, mloss, gloss, mloss + gloss]
+                curr_count = 0
+                curr_loss_gauss.zero_()
+                curr_loss_multi.zero_()
+            step += 1
+        self.sync_modules()
+
+    # ------------------------------------------------------------------ state <-> modules
+    @staticmethod
+    def _tensors(net: nn.Module):
+        return [(W.data, b.data) for W, b in net._weights()]
+
+    def sync_modules(self) -> None:
+        """Write the trained weights into ``diffusion_model._denoise_fn`` and the EMA into ``ema_model``."""
+        net = self.diffusion_model._denoise_fn
+        self.ema_model.to(self.device)
+        self._engine.train_export("weights", self._tensors(net))
+        self._engine.train_export("ema", self._tensors(self.ema_model))
+        torch.cuda.synchronize(self.device)
+
+    def finish(self) -> None:
+        """Detach the training state: the denoiser is re-packed (fp32 + bf16 images) on its next use."""
+        self.sync_modules()
+        self.diffusion_model._denoise_fn._synced_key = None
+
+
+def update_ema(target_params: Iterator[nn.Parameter], source_params: Iterator[nn.Parameter], rate: float = 0.999) -> None:
+    """TRAINER:138 for callers that hold module parameters (the trainer itself fuses this into mtk_train_apply)."""
+    with torch.no_grad():
+        for targ, src in zip(target_params, source_params):
+            targ.detach().mul_(rate).add_(src.detach(), alpha=1 - rate)

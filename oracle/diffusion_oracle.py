@@ -413,3 +413,58 @@ def multinomial_loss_floor(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0:
 
     kap = kappa_sum(lx0) + kappa_sum(block_log_softmax(model_out[:, Nn:], K))
     return (s.T / C) * ulp * kap
+
+
+# --------------------------------------------------------------------------- training (a19)
+def loss_and_grads(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], x0, t, eps, u):
+    """TRAINER:88-91: ``zero_grad; loss_multi + loss_gauss; backward`` with injected (t, eps, u).
+    Returns (grads by parameter name, loss_multi mean, loss_gauss mean).  The gradient is torch
+    autograd through the restated forward ops, i.e. exactly what the reference differentiates."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u)
+    (m_mean + g_mean).backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return grads, m_mean.detach(), g_mean.detach()
+
+
+def adamw_update(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float, wd: float,
+                 betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """torch.optim.AdamW's single-tensor update (TRAINER:47-51, :92), in place, same op sequence:
+    decoupled decay, lerp of exp_avg, addcmul of exp_avg_sq, bias corrections, addcdiv."""
+    b1, b2 = betas
+    p.mul_(1 - lr * wd)
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def annealed_lr(lr0: float, step: int, steps: int) -> float:
+    """TRAINER:58-68, the value set AFTER iteration ``step`` (0-based) and used by iteration step + 1."""
+    return lr0 * (1 - step / steps)
+
+
+def ema_update(ema: dict[str, torch.Tensor], params: dict[str, torch.Tensor], rate: float = 0.999) -> None:
+    """TRAINER:138-155."""
+    for k in ema:
+        ema[k].mul_(rate).add_(params[k], alpha=1 - rate)
+
+
+def train_loop(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], batches, lr0: float, wd: float, steps: int):
+    """TRAINER:96-135 on pre-drawn batches ``[(x0, t, eps, u)]``: returns (per-step [lm, lg], final params, EMA)."""
+    p = {k: v.detach().clone() for k, v in params.items()}
+    ema = {k: v.clone() for k, v in p.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    lr, hist = lr0, []
+    for step in range(steps):
+        x0, t, eps, u = batches[step]
+        g, lm, lg = loss_and_grads(s, K, Nn, p, x0, t, eps, u)
+        for k in p:
+            adamw_update(p[k], g[k], m[k], v2[k], step + 1, lr, wd)
+        lr = annealed_lr(lr0, step, steps)
+        ema_update(ema, p)
+        hist.append([float(lm), float(lg)])
+    return np.asarray(hist, dtype=np.float64), p, ema

@@ -1,0 +1,53 @@
+"""The oracle's training restatement (loss_and_grads / adamw_update / train_loop) against the reference's
+ClavaDDPMTrainer run captured in tests/golden/train_*.npz (tools/make_golden.py, gen_train)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_train(tag):
+    z = np.load(os.path.join(GOLD, f"train_{tag}.npz"))
+    c = {k: z[k] for k in z.files}
+    c["K"] = [int(k) for k in c["K"]]
+    c["Nn"], c["T"], c["steps"] = int(c["Nn"]), int(c["T"]), int(c["steps"])
+    c["d_layers"] = [int(v) for v in c["d_layers"]]
+    c["D"] = c["Nn"] + sum(c["K"])
+    c["batches"] = [(torch.from_numpy(c["x"][i]), torch.from_numpy(c["t"][i]), torch.from_numpy(c["eps"][i]), torch.from_numpy(c["u"][i]))
+                    for i in range(c["steps"])]
+    return c
+
+
+def flatten(params, n_layers):
+    return torch.cat([torch.cat([params[n + ".weight"].reshape(-1), params[n + ".bias"].reshape(-1)]) for n in orc.mlp_param_names(n_layers)])
+
+
+@pytest.mark.parametrize("tag", ["B_ragged", "A_numeric"])
+def test_train_loop_matches_reference(tag):
+    c = load_train(tag)
+    s = orc.make_schedule(c["T"], "cosine")
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    hist, p, ema = orc.train_loop(s, c["K"], c["Nn"], p0, c["batches"], float(c["lr"]), float(c["wd"]), c["steps"])
+    np.testing.assert_array_equal(hist.astype(np.float32), c["losses"].astype(np.float32))
+    n = len(c["d_layers"])
+    np.testing.assert_array_equal(flatten(p, n).numpy(), c["final"])
+    np.testing.assert_array_equal(flatten(ema, n).numpy(), c["ema"])
+
+
+def test_adamw_update_is_torch_adamw():
+    g = torch.Generator().manual_seed(3)
+    p = torch.randn((37, 11), generator=g)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=2e-3, weight_decay=1e-4)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn((37, 11), generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        orc.adamw_update(p, gr, m, v, step, 2e-3, 1e-4)
+        assert torch.equal(p, ref.detach())

@@ -237,7 +237,74 @@ def gen_case(tag, K, Nn, d_layers, T, B, sched="cosine", P=4, T_chain=None):
     print(f"case {tag}: B={B} D={Nn + S} means={m_mean.item():.6f},{g_mean.item():.6f}")
 
 
+def gen_train(tag, K, Nn, d_layers, T, B, steps, lr, wd, n_rows=99):
+    """The reference's ClavaDDPMTrainer (trainer.py) for `steps` iterations on a fixed synthetic table, every
+    random draw captured per iteration.  Stored: the batches, the draws, the two loss means per iteration and
+    the trained / EMA weights (flattened in oracle.mlp_param_names order, weight then bias)."""
+    import importlib
+
+    trainer_mod = importlib.import_module("midst_toolkit.models.clavaddpm.trainer")
+    K = np.asarray(K, dtype=np.int64)
+    C = len(K) if has_cat(K) else 0
+    S = int(K.sum())
+    g = torch.Generator().manual_seed(777)
+    diff, params = build(K, Nn, d_layers, T)
+    diff.train()
+    table = synth_rows(n_rows, K, Nn, g)
+    order = [torch.randint(0, n_rows, (B,), generator=g) for _ in range(steps)]
+
+    def batches():
+        for idx in order:
+            yield table[idx], torch.zeros(B, dtype=torch.long)
+
+    tr = trainer_mod.ClavaDDPMTrainer(diff, batches(), lr, wd, steps, device=CPU)
+    losses, draws = [], []
+    inner = tr._train_step
+
+    def spy(x, y):
+        log: list = []
+        with capture_rng(log):
+            lm, lg = inner(x, y)
+        losses.append([float(lm), float(lg)])
+        draws.append(log)
+        return lm, lg
+
+    tr._train_step = spy
+    torch.manual_seed(99)
+    tr.train()
+    ts, epss, us = [], [], []
+    for log in draws:
+        assert log[0][0] == "randint"
+        ts.append(log[0][1].numpy())
+        pos = 1
+        if Nn > 0:
+            assert log[pos][0] == "randn_like"
+            epss.append(log[pos][1].numpy())
+            pos += 1
+        if C:
+            us.append(torch.cat([e[1] for e in log[pos:pos + C]], dim=1).numpy())
+            pos += C
+        assert pos == len(log), (pos, len(log))
+    names = orc.mlp_param_names(len(d_layers))
+    sd, ema_sd = diff._denoise_fn.state_dict(), tr.ema_model.state_dict()
+    flat = lambda d: np.concatenate([np.concatenate([d[n + ".weight"].detach().numpy().ravel(), d[n + ".bias"].detach().numpy().ravel()]) for n in names])
+    np.savez_compressed(
+        os.path.join(OUT, f"train_{tag}.npz"), K=K, Nn=Nn, d_layers=np.asarray(d_layers), T=T, sched="cosine", lr=lr, wd=wd, steps=steps,
+        x=np.stack([table[i].numpy() for i in order]), t=np.stack(ts), eps=np.stack(epss) if epss else np.zeros((steps, B, 0), np.float32),
+        u=np.stack(us) if us else np.zeros((steps, B, 0), np.float32), losses=np.asarray(losses, dtype=np.float64),
+        final=flat(sd).astype(np.float32), ema=flat(ema_sd).astype(np.float32))
+    print(f"train {tag}: losses {losses[0]} -> {losses[-1]}")
+
+
 def main():
+    if "--train-only" not in sys.argv:
+        main_cases()
+    # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
+    gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
+    gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
+
+
+def main_cases():
     gen_schedule("cosine_1000", 1000, "cosine")
     gen_schedule("linear_100", 100, "linear")
     # A: the shipped pipeline's shape (numeric only, num_classes=[0]); also the Tartan-Federer shape
