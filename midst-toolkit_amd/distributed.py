@@ -1,0 +1,79 @@
+"""Host-side sharding for the three entry points.  One process per GPU; the only data-path
+collectives are the gather of results (scoring, sampling) and the gradient all-reduce (training, in trainer.py).
+
+Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL over xGMI) on the GPU box, ``gloo`` in the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def world() -> tuple[int, int]:
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of ``n`` units for ``rank``: the first ``n % world`` ranks hold one extra unit.
+    ``lo`` is also the ``row0`` handed to the kernels, which makes in-kernel Philox noise independent of the
+    number of GPUs."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_rows(local: Tensor, n_total: int, dim: int = 0) -> Tensor:
+    """All-gather blocks that were split with :func:`shard_range` along ``dim`` back into global order.
+    Equal blocks go through one ``all_gather_into_tensor``; ragged ones are padded to the largest block."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    local = local.movedim(dim, 0).contiguous()
+    sizes = [shard_range(n_total, r, ws)[1] - shard_range(n_total, r, ws)[0] for r in range(ws)]
+    assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
+    big = max(sizes)
+    if big != local.shape[0]:
+        pad = torch.zeros((big - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((ws * big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    if min(sizes) != big:
+        out = torch.cat([out[r * big: r * big + sizes[r]] for r in range(ws)], 0)
+    return out.movedim(0, dim)
+
+
+@torch.no_grad()
+def score_records_sharded(diffusion_model, features: Tensor, noise: Tensor, timesteps, additional_timestep: int = 0,
+                          precision: str | None = None) -> Tensor:
+    """:func:`scoring.score_records` over all ranks: every rank passes the SAME ``features`` ([N, .], host or device),
+    scores its contiguous block on its GPU and receives the full [n_t, N, P] score tensor."""
+    from .scoring import score_records
+
+    rank, ws = world()
+    lo, hi = shard_range(features.shape[0], rank, ws)
+    dev = diffusion_model.alphas.device
+    local = score_records(diffusion_model, features[lo:hi].to(dev), noise, timesteps, additional_timestep, precision)
+    return gather_rows(local, features.shape[0], dim=1)
+
+
+def sample_all_sharded(diffusion_model, num_samples: int, batch_size: int, target_dist: Tensor):
+    """``sample_all`` (GMD:1426) with the rows split over ranks; each rank runs its own T-loop, the only exchange is
+    the final gather of the [N, Nn + C] fp64 samples and their labels."""
+    rank, ws = world()
+    lo, hi = shard_range(num_samples, rank, ws)
+    x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist)
+    if ws == 1:
+        return x, y
+    dev = diffusion_model.alphas.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    return gather_rows(x.to(dev), num_samples).cpu(), gather_rows(y.to(dev), num_samples).cpu()
+
+
+def allreduce_gradients(grad_image: Tensor) -> None:
+    """Training's one exchange per iteration: SUM over ranks of the gradient image (each rank scaled its
+    contribution by 1 / global batch in mtk_train_step)."""
+    if world()[1] > 1:
+        dist.all_reduce(grad_image)

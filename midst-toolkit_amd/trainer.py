@@ -17,6 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from .diffusion import GaussianMultinomialDiffusion
+from .distributed import allreduce_gradients, world
 from .model import timestep_frequencies
 
 
@@ -58,9 +59,7 @@ class ClavaDDPMTrainer:
             raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
         self._engine = diffusion_model.engine()
         self.state = self._engine.train_attach(timestep_frequencies(net.timestep_dimension))
-        dist = torch.distributed
-        self._world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self._rank = dist.get_rank() if self._world > 1 else 0
+        self._rank, self._world = world()
 
     # ------------------------------------------------------------------ TRAINER:58
     def _anneal_learning_rate(self, step: int) -> None:
@@ -92,8 +91,7 @@ class ClavaDDPMTrainer:
         lm = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None
         lg = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None
         eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
-        if self._world > 1:
-            torch.distributed.all_reduce(self.state[1])  # the one exchange of an iteration
+        allreduce_gradients(self.state[1])  # the one exchange of an iteration
         g = self.optimizer.param_groups[0]
         self.optimizer.steps_done += 1
         eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)

@@ -215,3 +215,59 @@ def test_training_run_teacher_forced(tag):
         after = export(tr, "weights")
         for k in p:
             torch.testing.assert_close(after[k], p[k], rtol=2e-6, atol=1e-8)
+
+
+def _two_rank_body(rank, ws, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK=str(rank), WORLD_SIZE=str(ws))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import midst_toolkit_amd.distributed as D
+
+        c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[128, 128])
+        p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+        B = 512
+        x0, t, eps, u = [v.to(dev()) for v in big_batch(c, B)]
+        tr, d = build_trainer(c, p0)
+        assert (tr._rank, tr._world) == (rank, ws)
+        eng = tr._engine
+        eng.train_step(x0, t, eps, u, 1.0 / B, None, None)           # the whole batch on one device
+        full = export(tr, "grads")
+        lo, hi = D.shard_range(B, rank, ws)
+        eng.train_step(x0[lo:hi], t[lo:hi].contiguous(), eps[lo:hi], u[lo:hi], 1.0 / B, None, None, row0=lo)  # this rank's block
+        torch.cuda.synchronize()
+        D.allreduce_gradients(tr.state[1])
+        got = export(tr, "grads")
+        worst = max(float((got[k] - full[k]).norm() / full[k].norm().clamp_min(1e-30)) for k in full)
+        q.put((rank, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_gradient():
+    """Two ranks (sharing the one GPU of the test box, gloo all-reduce on device tensors): block gradients scaled by
+    1 / global batch and summed equal the single-device gradient of the whole batch."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import os
+
+    os.environ["MASTER_PORT"] = str(port)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_two_rank_body, args=(r, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        assert p.exitcode == 0, p.exitcode
+    res = dict(q.get() for _ in range(2))
+    assert res[0] < 2e-5 and res[1] < 2e-5, res
