@@ -8,6 +8,7 @@
 // Built with -ffp-contract=off: every fp32 expression below is evaluated with the same roundings
 // as the reference's eager tensor ops (no fused multiply-add), so categorical draws can match.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mtk_common.h"
 
@@ -388,9 +389,14 @@ __global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
             float best = -INFINITY;
             int arg = 0;
-            for (int i = 0; i < Kk; ++i) {
-                const float v = (a.u0 ? gumbel(a.u0[row * S + o + i]) : gumbel_fast(pu.uniform(o + i))) + 0.0f;
-                if (v > best || i == 0) { best = v; arg = i; }
+            if (a.u0) {
+                for (int i = 0; i < Kk; ++i) {
+                    const float v = gumbel(a.u0[row * S + o + i]) + 0.0f;
+                    if (v > best || i == 0) { best = v; arg = i; }
+                }
+            } else {  // in-kernel noise: the arg-max of K i.i.d. Gumbels is uniform over the K columns
+                arg = (int)(pu.uniform(k) * (float)Kk);
+                arg = arg > Kk - 1 ? Kk - 1 : arg;
             }
             a.z_idx[(int64_t)k * a.B + row] = arg;
             for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
@@ -417,7 +423,14 @@ __global__ __launch_bounds__(kBlock) void k_sample_decode(int64_t B, int Nn, int
 //     (tests/test_conditioning.py), so batch means agree and per-record values are closer to exact;
 //   * the true posterior takes three distinct values per block (x_0's column, x_t's column, the rest) and
 //     the prior two, so both are closed forms per block; only the model posterior is per column;
-//   * the reverse step skips the normaliser: argmax(g + logp) = argmax(g + unnormalised logp) per block.
+//   * the reverse step skips the normaliser: argmax(g + logp) = argmax(g + unnormalised logp) per block;
+//   * the model posterior is evaluated in probability space: with e_i = exp(logit_i - max), q_pred of the
+//     log-softmax is log(A e_i + Bc), A = acp_{t-1} / sum e, Bc = (1 - acp_{t-1}) / K (A = 1 / sum e, Bc = 0 at
+//     t = 0), so P_i = (A e_i + Bc) Q_i needs one exp per column (and one log where log P_i itself is summed);
+//   * blocks of at most kKCache columns are read from memory once and held in registers across the passes;
+//   * with in-kernel noise (no injected uniforms) categorical draws use ONE Philox word per block and the
+//     inverse CDF of the same distribution instead of K Gumbel variates (noising: two words — x_0's column
+//     with its closed-form probability, else uniform over the rest).
 // Used for throughput runs (in-kernel Philox noise has no reference stream to be bit-compatible with).
 // ================================================================================================
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
@@ -450,39 +463,163 @@ struct PhiloxNF {
     }
 };
 
+// one Philox word per use: word j of the row's stream
+struct PhiloxW {
+    uint64_t seed, row;
+    uint32_t stream;
+    int have;
+    uint4 r;
+    __device__ __forceinline__ PhiloxW(uint64_t s, uint64_t rw, uint32_t st) : seed(s), row(rw), stream(st), have(-1) {}
+    __device__ __forceinline__ float uniform(int j) {
+        if ((j >> 2) != have) {
+            have = j >> 2;
+            r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+        }
+        const uint32_t w = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
+        return mtk_u01(w);
+    }
+};
+
+// The fast kernels are latency-bound unless loads are batched: a lane issues its loads in groups (kGroup numeric
+// columns, or the kKCache logits of the NEXT categorical block while the current one is being reduced) so that
+// several memory round trips are in flight per wave instead of one.
+constexpr int kGroup = 8;
+constexpr int kKCache = 16;
+
+// raw logits of one categorical block, held in registers when the block has at most kKCache columns
+struct BlockRaw {
+    float v[kKCache];
+    __device__ __forceinline__ void load(const float* mc, int64_t cs, int Kk) {
+#pragma unroll
+        for (int i = 0; i < kKCache; ++i) v[i] = (i < Kk) ? mc[i * cs] : -INFINITY;
+    }
+};
+// e_i = exp(logit_i - max) and their sum, from registers (CACHED) or recomputed from memory in every pass
+template <bool CACHED>
+struct BlockExp {
+    float e[CACHED ? kKCache : 1];
+    const float* mc;
+    int64_t cs;
+    int Kk;
+    float mx, sum;
+    __device__ __forceinline__ BlockExp(const BlockRaw& raw, const float* mc_, int64_t cs_, int Kk_) : mc(mc_), cs(cs_), Kk(Kk_) {
+        mx = -INFINITY;
+        sum = 0.0f;
+        if (CACHED) {
+#pragma unroll
+            for (int i = 0; i < kKCache; ++i) mx = fmaxf(mx, raw.v[i]);
+#pragma unroll
+            for (int i = 0; i < kKCache; ++i) {
+                e[i] = __expf(raw.v[i] - mx);  // 0 for the padding columns
+                sum += e[i];
+            }
+        } else {
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * cs]);
+            for (int i = 0; i < Kk; ++i) sum += __expf(mc[i * cs] - mx);
+        }
+    }
+    template <class F>
+    __device__ __forceinline__ void each(F&& f) const {
+        if (CACHED) {
+#pragma unroll
+            for (int i = 0; i < kKCache; ++i)
+                if (i < Kk) f(i, e[i]);
+        } else {
+            for (int i = 0; i < Kk; ++i) f(i, __expf(mc[i * cs] - mx));
+        }
+    }
+};
+struct CachedTag { static constexpr bool value = true; };
+struct StreamTag { static constexpr bool value = false; };
+
 template <bool LDS_ROWS>
 __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const int t = (int)a.t[row];
-        const SchedRow sr = s.rows[t];
         const float* xr = a.x0 + row * a.x0_ld;
         float* xo = a.x_in + row * a.xi_rs;
-        PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
-        PhiloxU pu(a.seed, a.row0 + row, MTK_STREAM_U);
-        for (int j = 0; j < Nn; ++j) {
-            const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
-            xo[j * a.xi_cs] = sr.sqrt_acp * xr[j] + sr.sqrt_1m_acp * e;
+        // first group of inputs in flight before anything is consumed
+        float xv[kGroup], ev[kGroup];
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+            xv[i] = (i < Nn) ? xr[i] : 0.0f;
+            ev[i] = (a.eps && i < Nn) ? a.eps[row * Nn + i] : 0.0f;
         }
-        for (int k = 0; k < C; ++k) {
-            const int o = s.off[k], Kk = s.off[k + 1] - o;
-            const int c0 = (int)(long long)xr[Nn + k];
-            const float c = sr.log_1m_acp - s.logK[k];
-            const float hot = lae_f(0.0f + sr.log_acp, c);
-            const float cold = lae_f(MTK_LOG_TINY + sr.log_acp, c);
-            float best = -INFINITY;
-            int arg = 0;
-            for (int i = 0; i < Kk; ++i) {
-                const float uu = a.u ? a.u[row * S + o + i] : pu.uniform(o + i);
-                const float v = gumbel_fast(uu) + (i == c0 ? hot : cold);
-                if (v > best || i == 0) { best = v; arg = i; }
+        const SchedRow sr = s.rows[t];
+        PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
+        PhiloxW pu(a.seed, a.row0 + row, MTK_STREAM_U);
+        for (int j0 = 0; j0 < Nn; j0 += kGroup) {
+            float xn[kGroup], en[kGroup];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {  // next group
+                const int j = j0 + kGroup + i;
+                xn[i] = (j < Nn) ? xr[j] : 0.0f;
+                en[i] = (a.eps && j < Nn) ? a.eps[row * Nn + j] : 0.0f;
             }
-            a.xt_idx[(int64_t)k * a.B + row] = arg;
-            for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {
+                const int j = j0 + i;
+                if (j < Nn) {
+                    const float e = a.eps ? ev[i] : pn.normal(j);
+                    xo[j * a.xi_cs] = sr.sqrt_acp * xv[i] + sr.sqrt_1m_acp * e;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) { xv[i] = xn[i]; ev[i] = en[i]; }
+        }
+        if (a.u) {  // injected uniforms: the reference's Gumbel arg-max
+            for (int k = 0; k < C; ++k) {
+                const int o = s.off[k], Kk = s.off[k + 1] - o;
+                const int c0 = (int)(long long)xr[Nn + k];
+                const float c = sr.log_1m_acp - s.logK[k];
+                const float hot = lae_f(0.0f + sr.log_acp, c);
+                const float cold = lae_f(MTK_LOG_TINY + sr.log_acp, c);
+                float best = -INFINITY;
+                int arg = 0;
+                for (int i = 0; i < Kk; ++i) {
+                    const float v = gumbel_fast(a.u[row * S + o + i]) + (i == c0 ? hot : cold);
+                    if (v > best || i == 0) { best = v; arg = i; }
+                }
+                a.xt_idx[(int64_t)k * a.B + row] = arg;
+                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+            }
+            continue;
+        }
+        // in-kernel noise.  q(x_t | x_0) = acp onehot(x_0) + (1 - acp) / K: x_0 with probability p0, else uniform over
+        // the other columns; two Philox words per block.  x_0's codes are fetched kGroup blocks at a time.
+        const float acp = fexp(sr.log_acp);
+        for (int k0 = 0; k0 < C; k0 += kGroup) {
+            float cv[kGroup];
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) cv[i] = (k0 + i < C) ? xr[Nn + k0 + i] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) {
+                const int k = k0 + i;
+                if (k < C) {
+                    const int o = s.off[k], Kk = s.off[k + 1] - o;
+                    const int c0 = (int)(long long)cv[i];
+                    const float pc = fexp(sr.log_1m_acp - s.logK[k]);  // (1 - acp) / K
+                    const float ph = acp + pc;
+                    const float p0 = ph / (ph + (float)(Kk - 1) * pc);
+                    const float u1 = pu.uniform(2 * k), u2 = pu.uniform(2 * k + 1);
+                    int arg = c0;
+                    if (u1 >= p0 && Kk > 1) {
+                        int j = (int)(u2 * (float)(Kk - 1));
+                        j = j > Kk - 2 ? Kk - 2 : j;
+                        arg = j + (j >= c0 ? 1 : 0);
+                    }
+                    a.xt_idx[(int64_t)k * a.B + row] = arg;
+                    float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
+                    for (int c = 0; c < Kk; ++c) xc[c * a.xi_cs] = (c == arg) ? 0.0f : MTK_LOG_TINY;
+                }
+            }
         }
     }
 }
+
+struct TruePost { float lt_c0, lt_ct, w_c0, w_ct, w_cc, w_sum, self; };
 
 template <bool LDS_ROWS>
 __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
@@ -492,71 +629,127 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const int t = (int)a.t[row];
         const float* mo = a.mo + row * a.mo_rs;
+        const float* xr = a.x0 ? a.x0 + row * a.x0_ld : nullptr;
+        const bool multi = a.loss_multi && C > 0;
+        // the first categorical block's inputs go out before the Gaussian part is consumed
+        BlockRaw raw;
+        int c0 = 0, ct = 0;
+        if (multi) {
+            raw.load(mo + (int64_t)Nn * a.mo_cs, a.mo_cs, s.off[1]);
+            c0 = (int)(long long)xr[Nn];
+            ct = a.xt_idx[row];
+        }
         if (a.loss_gauss && Nn > 0) {
             PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
             float acc = 0.0f;
-            for (int j = 0; j < Nn; ++j) {
-                const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
-                const float df = e - mo[j * a.mo_cs];
-                acc += df * df;
+            for (int j0 = 0; j0 < Nn; j0 += kGroup) {
+                float mv[kGroup], ev[kGroup];
+#pragma unroll
+                for (int i = 0; i < kGroup; ++i) {
+                    const int j = j0 + i;
+                    mv[i] = (j < Nn) ? mo[j * a.mo_cs] : 0.0f;
+                    ev[i] = (a.eps && j < Nn) ? a.eps[row * Nn + j] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < kGroup; ++i) {
+                    const int j = j0 + i;
+                    if (j < Nn) {
+                        const float df = (a.eps ? ev[i] : pn.normal(j)) - mv[i];
+                        acc += df * df;
+                    }
+                }
             }
             a.loss_gauss[row] = acc / (float)Nn;
         }
-        if (!a.loss_multi || C == 0) continue;
+        if (!multi) continue;
         const SchedRow st = s.rows[t];
         const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
-        const float* xr = a.x0 + row * a.x0_ld;
+        const float acp1 = (t == 0) ? 1.0f : fexp(s1.log_acp);
         float kl = 0.0f, nll = 0.0f, prior = 0.0f;
+        int Kc = -1;
+        TruePost tpE{}, tpN{};
+        float logK = 0.0f, q_hot = 0.0f, q_cold = 0.0f, e_hot = 0.0f, e_cold = 0.0f, Bc = 0.0f, Qh = 0.0f, Qc = 0.0f, prior_k = 0.0f;
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
-            const float logK = s.logK[k];
-            const int c0 = (int)(long long)xr[Nn + k];
-            const int ct = a.xt_idx[(int64_t)k * a.B + row];
             const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
-            const float cq = st.log_1m_alpha - logK;
-            const float q_hot = lae_f(0.0f + st.log_alpha, cq), q_cold = lae_f(MTK_LOG_TINY + st.log_alpha, cq);
-            const float ce = s1.log_1m_acp - logK;
-            const float e_hot = (t == 0) ? 0.0f : lae_f(0.0f + s1.log_acp, ce);
-            const float e_cold = (t == 0) ? MTK_LOG_TINY : lae_f(MTK_LOG_TINY + s1.log_acp, ce);
-            // true posterior: three distinct unnormalised values, closed-form normaliser
-            const float v_c0 = e_hot + ((c0 == ct) ? q_hot : q_cold);  // column of x_0
-            const float v_ct = e_cold + q_hot;                          // column of x_t (when != x_0)
-            const float v_cc = e_cold + q_cold;                         // every other column
-            const int n_cc = Kk - ((c0 == ct) ? 1 : 2);
-            const float m_t = fmaxf(v_c0, fmaxf(v_ct, v_cc));
-            float b_t = fexp(v_c0 - m_t) + (float)n_cc * fexp(v_cc - m_t);
-            if (c0 != ct) b_t += fexp(v_ct - m_t);
-            const float lse_t = m_t + flog(b_t);
-            const float lt_c0 = v_c0 - lse_t, lt_ct = v_ct - lse_t, lt_cc = v_cc - lse_t;
-            const float w_c0 = fexp(lt_c0), w_ct = fexp(lt_ct), w_cc = fexp(lt_cc);
-            // model posterior: log-softmax of the logits, one pass for the normaliser and the KL sums
-            float mx = -INFINITY;
-            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
-            float sum = 0.0f;
-            for (int i = 0; i < Kk; ++i) sum += fexp(mc[i * a.mo_cs] - mx);
-            const float lsum = flog(sum);
-            // shift of the model block: its maximum is at the largest logit or at x_t's column; bound it by
-            // the largest logit's value with q_hot (>= every column's value)
-            const float ev_top = (t == 0) ? -lsum : lae_f(-lsum + s1.log_acp, ce);
-            const float m_m = ev_top + q_hot;
-            float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
-            for (int i = 0; i < Kk; ++i) {
-                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
-                const float ev = (t == 0) ? lsm : lae_f(lsm + s1.log_acp, ce);
-                const float un = ev + ((i == ct) ? q_hot : q_cold);
-                b_m += fexp(un - m_m);
-                const float lt = (i == c0) ? lt_c0 : ((i == ct) ? lt_ct : lt_cc);
-                const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
-                acc_kl += w * (lt - un);
-                if (i == c0) un_c0 = un;
+            // next block's inputs
+            BlockRaw nxt;
+            int c0n = 0, ctn = 0;
+            if (k + 1 < C) {
+                nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
+                c0n = (int)(long long)xr[Nn + k + 1];
+                ctn = a.xt_idx[(int64_t)(k + 1) * a.B + row];
             }
-            const float lse_m = m_m + flog(b_m);
-            const float w_sum = w_c0 + (float)n_cc * w_cc + ((c0 != ct) ? w_ct : 0.0f);
-            kl += acc_kl + lse_m * w_sum;          // sum_i e^{lt_i} (lt_i - (un_i - lse_m))
-            nll += un_c0 - lse_m;                  // log-probability of x_0 (columns weighted 1e-30 dropped)
-            const float cT = srT.log_1m_acp - logK;
-            const float p_hot = lae_f(0.0f + srT.log_acp, cT), p_cold = lae_f(MTK_LOG_TINY + srT.log_acp, cT);
-            prior += fexp(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (fexp(p_cold) * (p_cold + logK));
+            // constants of (t, K): recomputed only when K changes from one block to the next (K is wave-uniform)
+            if (Kk != Kc) {
+                Kc = Kk;
+                logK = s.logK[k];
+                const float cq = st.log_1m_alpha - logK;
+                q_hot = lae_f(0.0f + st.log_alpha, cq);
+                q_cold = lae_f(MTK_LOG_TINY + st.log_alpha, cq);
+                const float ce = s1.log_1m_acp - logK;
+                e_hot = (t == 0) ? 0.0f : lae_f(0.0f + s1.log_acp, ce);
+                e_cold = (t == 0) ? MTK_LOG_TINY : lae_f(MTK_LOG_TINY + s1.log_acp, ce);
+                Bc = (t == 0) ? 0.0f : fexp(ce);
+                Qh = fexp(q_hot);
+                Qc = fexp(q_cold);
+                const float cT = srT.log_1m_acp - logK;
+                const float p_hot = lae_f(0.0f + srT.log_acp, cT), p_cold = lae_f(MTK_LOG_TINY + srT.log_acp, cT);
+                prior_k = fexp(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (fexp(p_cold) * (p_cold + logK));
+                // true posterior (GMD:781 on the one-hot x_0): three distinct unnormalised values — x_0's column, x_t's
+                // column when it differs, every other column — with a closed-form normaliser; both variants
+                auto post = [&](bool same, TruePost& o_) {
+                    const float v_c0 = e_hot + (same ? q_hot : q_cold);
+                    const float v_ct = e_cold + q_hot;
+                    const float v_cc = e_cold + q_cold;
+                    const int n_cc = Kk - (same ? 1 : 2);
+                    const float m_t = fmaxf(v_c0, fmaxf(v_ct, v_cc));
+                    float b_t = fexp(v_c0 - m_t) + (float)n_cc * fexp(v_cc - m_t);
+                    if (!same) b_t += fexp(v_ct - m_t);
+                    const float lse_t = m_t + flog(b_t);
+                    o_.lt_c0 = v_c0 - lse_t;
+                    o_.lt_ct = v_ct - lse_t;
+                    const float lt_cc = v_cc - lse_t;
+                    o_.w_c0 = fexp(o_.lt_c0);
+                    o_.w_ct = fexp(o_.lt_ct);
+                    o_.w_cc = fexp(lt_cc);
+                    o_.w_sum = o_.w_c0 + (float)n_cc * o_.w_cc + (same ? 0.0f : o_.w_ct);
+                    o_.self = o_.w_c0 * o_.lt_c0 + (float)n_cc * (o_.w_cc * lt_cc) + (same ? 0.0f : o_.w_ct * o_.lt_ct);
+                };
+                post(true, tpE);
+                post(false, tpN);
+            }
+            // true posterior of this block: the x_t == x_0 or the x_t != x_0 variant
+            const bool eq = (c0 == ct);
+            const float lt_c0 = eq ? tpE.lt_c0 : tpN.lt_c0, w_c0 = eq ? tpE.w_c0 : tpN.w_c0;
+            const float lt_ct = tpN.lt_ct, w_ct = tpN.w_ct;
+            const float w_cc = eq ? tpE.w_cc : tpN.w_cc;
+            const float self = eq ? tpE.self : tpN.self, w_sum = eq ? tpE.w_sum : tpN.w_sum;
+            (void)lt_c0; (void)lt_ct;
+            // model posterior in probability space: P_i = (A e_i + Bc) Q_i, log p_i = log P_i - log sum P
+            float total = 0.0f, sum_log_cc = 0.0f, lp_c0 = 0.0f, lp_ct = 0.0f;
+            auto model = [&](auto tag) {
+                const BlockExp<decltype(tag)::value> be(raw, mc, a.mo_cs, Kk);
+                const float A = acp1 / be.sum;
+                be.each([&](int i, float e) {
+                    const float P = (A * e + Bc) * ((i == ct) ? Qh : Qc);
+                    total += P;
+                    const float lp = flog(P);
+                    if (i == c0) lp_c0 = lp;
+                    else if (i == ct) lp_ct = lp;
+                    else sum_log_cc += lp;
+                });
+            };
+            if (Kk <= kKCache) model(CachedTag{}); else model(StreamTag{});
+            const float lse_m = flog(total);
+            float cross = w_c0 * lp_c0 + w_cc * sum_log_cc;              // sum_i w_i log P_i
+            if (!eq) cross += w_ct * lp_ct;
+            kl += (self - cross) + lse_m * w_sum;                        // self = sum_i w_i log w_i
+            nll += lp_c0 - lse_m;                  // log-probability of x_0 (columns weighted 1e-30 dropped)
+            prior += prior_k;
+            raw = nxt;
+            c0 = c0n;
+            ct = ctn;
         }
         const float lt = (t == 0) ? -nll : kl;
         a.loss_multi[row] = (lt * (float)T + prior) / (float)C;
@@ -567,60 +760,120 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
     const Staged s = stage_tables<false>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S, t = a.t;
     const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)t, stream_u = stream_n + 1u;
+    constexpr int G = 4;  // numeric columns per load group (fp64 state: 2 registers each)
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const float* mo = a.mo + row * a.mo_rs;
         float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
         PhiloxNF pn(a.seed, a.row0 + row, stream_n);
-        PhiloxU pu(a.seed, a.row0 + row, stream_u);
-        for (int j = 0; j < Nn; ++j) {  // the numeric state stays fp64 (SURVEY finding 0.4)
-            const float eh = mo[j * a.mo_cs];
-            double* zp = a.z + (int64_t)j * a.B + row;
-            const double zj = *zp;
-            double nz;
-            if (a.noise) {
-                nz = a.noise_f64 ? reinterpret_cast<const double*>(a.noise)[row * Nn + j]
-                                 : (double)reinterpret_cast<const float*>(a.noise)[row * Nn + j];
-            } else {
-                nz = (double)pn.normal(j);
-            }
-            double mean;
-            if (a.first) {
-                const float zf = (float)zj;
-                const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
-                mean = (double)(a.coef1 * x0h + a.coef2 * zf);
-            } else {
-                const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
-                mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
-            }
-            const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
-            *zp = zn;
-            if (xo) xo[j * a.xi_cs] = (float)zn;
+        PhiloxW pu(a.seed, a.row0 + row, stream_u);
+        // the first categorical block's inputs go out before the numeric part is consumed
+        BlockRaw raw;
+        int cz = 0;
+        if (C > 0 && !a.u) {
+            raw.load(mo + (int64_t)Nn * a.mo_cs, a.mo_cs, s.off[1]);
+            cz = a.z_idx[row];
         }
+        for (int j0 = 0; j0 < Nn; j0 += G) {  // the numeric state stays fp64 (SURVEY finding 0.4)
+            float eh[G];
+            double zv[G], nv[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int j = j0 + i;
+                eh[i] = (j < Nn) ? mo[j * a.mo_cs] : 0.0f;
+                zv[i] = (j < Nn) ? a.z[(int64_t)j * a.B + row] : 0.0;
+                nv[i] = 0.0;
+                if (a.noise && j < Nn)
+                    nv[i] = a.noise_f64 ? reinterpret_cast<const double*>(a.noise)[row * Nn + j]
+                                        : (double)reinterpret_cast<const float*>(a.noise)[row * Nn + j];
+            }
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int j = j0 + i;
+                if (j < Nn) {
+                    const double zj = zv[i];
+                    const double nz = a.noise ? nv[i] : (double)pn.normal(j);
+                    double mean;
+                    if (a.first) {
+                        const float zf = (float)zj;
+                        const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh[i];
+                        mean = (double)(a.coef1 * x0h + a.coef2 * zf);
+                    } else {
+                        const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh[i]);
+                        mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+                    }
+                    const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
+                    a.z[(int64_t)j * a.B + row] = zn;
+                    if (xo) xo[j * a.xi_cs] = (float)zn;
+                }
+            }
+        }
+        if (a.u) {  // injected uniforms: Gumbel arg-max over the unnormalised log posterior
+            for (int k = 0; k < C; ++k) {
+                const int o = s.off[k], Kk = s.off[k + 1] - o;
+                const float logK = s.logK[k];
+                const int czk = a.z_idx[(int64_t)k * a.B + row];
+                const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+                const float cq = a.log_1m_alpha - logK;
+                const float ce = a.log_1m_acp_prev - logK;
+                float mx = -INFINITY;
+                for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+                const float q_hot = lae_f(0.0f + a.log_alpha, cq), q_cold = lae_f(MTK_LOG_TINY + a.log_alpha, cq);
+                float sum = 0.0f;
+                for (int i = 0; i < Kk; ++i) sum += fexp(mc[i * a.mo_cs] - mx);
+                const float lsum = flog(sum);
+                float best = -INFINITY;
+                int arg = 0;
+                for (int i = 0; i < Kk; ++i) {
+                    const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                    const float ev = (t == 0) ? lsm : lae_f(lsm + a.log_acp_prev, ce);
+                    const float v = gumbel_fast(a.u[row * S + o + i]) + (ev + ((i == czk) ? q_hot : q_cold));
+                    if (v > best || i == 0) { best = v; arg = i; }
+                }
+                a.z_idx[(int64_t)k * a.B + row] = arg;
+                if (xo)
+                    for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+            }
+            continue;
+        }
+        // in-kernel noise: one Philox word per block, inverse CDF of P_i = (A e_i + Bc) Q_i
+        const float acp1 = (t == 0) ? 1.0f : fexp(a.log_acp_prev);
+        const float al = fexp(a.log_alpha);
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
-            const float logK = s.logK[k];
-            const int cz = a.z_idx[(int64_t)k * a.B + row];
             const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
-            const float cq = a.log_1m_alpha - logK;
-            const float q_hot = lae_f(0.0f + a.log_alpha, cq), q_cold = lae_f(MTK_LOG_TINY + a.log_alpha, cq);
-            const float ce = a.log_1m_acp_prev - logK;
-            float mx = -INFINITY;
-            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
-            float sum = 0.0f;
-            for (int i = 0; i < Kk; ++i) sum += fexp(mc[i * a.mo_cs] - mx);
-            const float lsum = flog(sum);
-            float best = -INFINITY;
-            int arg = 0;
-            for (int i = 0; i < Kk; ++i) {
-                const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
-                const float ev = (t == 0) ? lsm : lae_f(lsm + a.log_acp_prev, ce);
-                const float uu = a.u ? a.u[row * S + o + i] : pu.uniform(o + i);
-                const float v = gumbel_fast(uu) + (ev + ((i == cz) ? q_hot : q_cold));
-                if (v > best || i == 0) { best = v; arg = i; }
+            BlockRaw nxt;
+            int czn = 0;
+            if (k + 1 < C) {
+                nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
+                czn = a.z_idx[(int64_t)(k + 1) * a.B + row];
             }
+            const float logK = s.logK[k];
+            const float qc = fexp(a.log_1m_alpha - logK);
+            const float Qh = al + qc, Qc = qc;
+            const float Bc = (t == 0) ? 0.0f : fexp(a.log_1m_acp_prev - logK);
+            const float u1 = pu.uniform(k);
+            int arg = Kk - 1;
+            auto draw = [&](auto tag) {
+                const BlockExp<decltype(tag)::value> be(raw, mc, a.mo_cs, Kk);
+                const float A = acp1 / be.sum;
+                float total = 0.0f;
+                be.each([&](int i, float e) { total += (A * e + Bc) * ((i == cz) ? Qh : Qc); });
+                const float target = u1 * total;
+                float cum = 0.0f;
+                bool found = false;
+                be.each([&](int i, float e) {
+                    cum += (A * e + Bc) * ((i == cz) ? Qh : Qc);
+                    if (!found && cum > target) { arg = i; found = true; }
+                });
+            };
+            if (Kk <= kKCache) draw(CachedTag{}); else draw(StreamTag{});
             a.z_idx[(int64_t)k * a.B + row] = arg;
-            if (xo)
-                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+            if (xo) {
+                float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
+                for (int i = 0; i < Kk; ++i) xc[i * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+            }
+            raw = nxt;
+            cz = czn;
         }
     }
 }
@@ -777,7 +1030,7 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
     LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
                    ctx->Nn > 0 ? (float)(2.0 * inv_global_batch / ctx->Nn) : 0.0f,
                    ctx->C > 0 ? (float)((double)ctx->T * inv_global_batch / ctx->C) : 0.0f, seed, row0};
-    const bool lds = ctx->T <= MTK_LDS_T_MAX;
+    const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
     auto k = ctx->fast_math ? (lds ? k_loss_grad<true, true> : k_loss_grad<false, true>) : (lds ? k_loss_grad<true, false> : k_loss_grad<false, false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), stream, a);
     MTK_HIP(hipGetLastError());
@@ -794,7 +1047,7 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
     QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0};
-    const bool lds = ctx->T <= MTK_LDS_T_MAX;
+    const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
     auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true> : k_q_sample_fast<false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
@@ -811,7 +1064,7 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
     LossArgs a{ctx->dev(), B, model_out, mo_rs, mo_cs, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, seed, row0};
-    const bool lds = ctx->T <= MTK_LDS_T_MAX;
+    const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
     auto k = ctx->fast_math ? (lds ? k_loss_rows_fast<true> : k_loss_rows_fast<false>) : (lds ? k_loss_rows<true> : k_loss_rows<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());

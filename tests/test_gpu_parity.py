@@ -453,3 +453,54 @@ def test_fast_math_philox_statistics():
     se_m = float(lm_ref.std()) / B ** 0.5
     assert abs(float(lg.mean()) - float(lg_ref.mean())) < 6 * se_g
     assert abs(float(lm.mean()) - float(lm_ref.mean())) < 6 * se_m
+
+
+def test_philox_categorical_distributions():
+    """In-kernel noise draws categories by inverse CDF from one Philox word per block (noising: closed form).
+    Same distributions as the reference's Gumbel arg-max: empirical frequencies over 2^18 identical rows
+    must sit within 5 sigma of the oracle's probabilities, for noising, the reverse step and the initial draw."""
+    c = load_case("B_ragged")
+    B, Nn, C, D, K = 1 << 18, c["Nn"], c["C"], c["D"], c["K"]
+    d = build(c)
+    d.rng = "philox"
+    eng = d.engine()
+    s = orc.make_schedule(c["T"], c["sched"])
+    off = orc.offsets_of(K)
+    g = torch.Generator().manual_seed(3)
+
+    def check(idx, probs, what):
+        for k in range(C):
+            p = probs[off[k]:off[k + 1]].double()
+            p = p / p.sum()
+            f = torch.bincount(idx[k].cpu().long(), minlength=int(K[k])).double() / B
+            sig = (p * (1 - p) / B).sqrt() + 1e-9
+            assert bool(((f - p).abs() <= 5 * sig + 2e-6).all()), f"{what} block {k}: {f.tolist()} vs {p.tolist()}"
+
+    for tval in (0, 40, 500, 999):
+        row = torch.cat([torch.zeros(Nn)] + [torch.tensor([float(int(k) // 2)]) for k in K])
+        x0 = row.repeat(B, 1).to(dev())
+        t = torch.full((B,), tval, dtype=torch.long, device=dev())
+        x_in = torch.empty((D, B), device=dev())
+        idx = torch.empty((C, B), dtype=torch.int32, device=dev())
+        eng.q_sample(x0, t, None, None, x_in, (1, B), idx, seed=77 + tval)
+        logq = orc.q_pred(s, orc.log_onehot(row[None, Nn:].long(), K), torch.tensor([tval]), orc.log_k_expanded(K))[0]
+        check(idx, logq.exp(), f"q_sample t={tval}")
+        # the model input image is the log-one-hot of the drawn categories
+        want_img = orc.log_onehot(idx.t().cpu().long()[:64], K)
+        assert torch.equal(x_in[Nn:, :64].t().cpu(), want_img)
+        # reverse step from that state with one fixed logit row
+        mo = (torch.randn((1, D), generator=g) * 2).repeat(B, 1)
+        zi = torch.stack([torch.full((B,), int(k) - 1) for k in K], 1)
+        logp = orc.q_posterior(s, orc.block_log_softmax(mo[:1, Nn:], K), orc.log_onehot(zi[:1], K), torch.tensor([tval]), K)[0]
+        z = torch.zeros((max(Nn, 1), B), dtype=torch.float64, device=dev())
+        zid = zi.t().contiguous().int().to(dev())
+        eng.p_sample_step(B, tval, False, colmajor(mo), (1, B), z, zid, None, None, x_in, (1, B), seed=5 + tval)
+        check(zid, logp.exp(), f"p_sample_step t={tval}")
+        zs = z[:Nn].cpu()
+        want_mean = orc.gaussian_p_step(s, mo[:1, :Nn], torch.zeros((1, Nn), dtype=torch.float64), tval, torch.zeros((1, Nn), dtype=torch.float64))[0]
+        assert bool(((zs.mean(1) - want_mean).abs() <= 6 * zs.std(1) / B ** 0.5 + 1e-6).all())
+    z = torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev())
+    zid = torch.empty((C, B), dtype=torch.int32, device=dev())
+    eng.sample_init(B, None, None, z, zid, x_in, (1, B), seed=9)
+    check(zid, torch.ones(int(np.sum(K))), "sample_init")
+    assert abs(float(z[:Nn].mean())) < 6 / (B * Nn) ** 0.5 and abs(float(z[:Nn].std()) - 1) < 0.01
