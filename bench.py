@@ -128,6 +128,13 @@ def main():
         dt = float(tmax)
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))  # HIP events on the launch stream
 
+    # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same configuration
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r1_pmc_fused.json")
+    if a.precision == "bf16" and a.records == 100_000 and a.nt == 10 and a.hidden == 512 and os.path.exists(pmc):
+        with open(pmc) as f:
+            rec = json.load(f)
+        traffic = rec["fetch_bytes_per_launch_corrected_x2"] + rec["write_bytes_per_launch"]
     evals_step = a.records * a.nt * P
     fl = flops_per_eval(Nn, 128, hidden)
     achieved = evals_step * fl / (kern_ms * 1e-3) / 1e12
@@ -140,7 +147,7 @@ def main():
         "config": {"workload": f"Tartan-Federer denoising-loss scoring (BASELINE configs[1]): {a.records} records/GPU x {a.nt} timesteps/step, "
                                f"P=1, 20 numeric features, 4x{a.hidden} MLPDiffusion, T=1000; random-init weights",
                    "records_per_gpu": a.records, "timesteps_per_step": a.nt, "hidden": a.hidden, "sharding": f"records/{world}"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "kernel": "fused tf-score kernel (noise + denoiser + MSE)" if a.precision == "bf16" else "layered f32-MFMA denoiser (whole step)",
                      "flops_per_eval": fl, "kernel_ms": kern_ms},
     }
