@@ -102,6 +102,8 @@ struct mtk_ctx {
     // workspace of the unfused Tartan-Federer path (x_t and eps_hat, row-major [rows][Nn])
     float* tf_ws[2] = {nullptr, nullptr};
     size_t tf_ws_elems = 0;
+    float* tf_pack = nullptr;  // compact [B][round_up(Nn,4)] copy of the records for the fused Tartan-Federer kernel
+    size_t tf_pack_elems = 0;
     TrainState train;
 
     DevTables dev() const { return DevTables{d_rows, d_off, d_logK, T, Nn, C, S}; }

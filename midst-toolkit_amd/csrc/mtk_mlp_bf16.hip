@@ -55,6 +55,7 @@ struct FusedArgs {
     float* out; int64_t o_rs, o_cs;
     // mode 1
     int64_t BP; int P; int64_t x_ld;
+    int nk; int64_t tiles_per_k;  // timesteps of this launch; 128-row tiles per timestep (tiles never straddle one)
     const float* noise;
     float* score;
     const SchedRow* sched;
@@ -83,18 +84,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 // consumed, chunk c+1 has landed, chunk c+2 is in flight and chunk c+3 is being requested, one 1-KiB piece per
 // wave every fourth MFMA (an LDS-DMA costs the issuing wave tens of cycles, so the pieces are spread out rather
 // than issued as a burst that would drain the matrix pipe).
+template <bool DIAG>
 struct Pipe {
     const unsigned char* src;  // wfrag + lane * 16
     int total_chunks;
     int next;                  // chunk of the stream being requested
     unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer being filled
     int lane, wid;
-    int exp;
+    int exp_;                  // diagnostic switches, honoured only by the DIAG (stamp) build
+    __device__ __forceinline__ int exp() const { return DIAG ? exp_ : 0; }
 
     // piece K (0..7) of the chunk being requested: fragment wid + 4 K; 64 lanes x 16 B, dest = base + lane * 16
     template <int K>
     __device__ __forceinline__ void piece() {
-        if (!(exp & 1)) {
+        if (!(exp() & 1)) {
             const int f = wid + 4 * K;
             const unsigned dst = __builtin_amdgcn_readfirstlane(dma + (unsigned)f * kFragBytes);
             const unsigned char* gp = src + (size_t)next * kChunkBytes + (size_t)f * kFragBytes;
@@ -117,7 +120,7 @@ struct Pipe {
     // (chunk m+2) have landed, so chunk m+1 is complete; the barrier extends that to every wave and also says
     // every wave is done with chunk m-1, whose buffer the following pieces (chunk m+3) overwrite.
     __device__ __forceinline__ void sync() {
-        if (!(exp & 2)) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if (!(exp() & 2)) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     }
     __device__ __forceinline__ void rotate() { rd = (rd + kChunkBytes == kBufs * kChunkBytes) ? 0u : rd + kChunkBytes; }
     __device__ __forceinline__ bf16x8 ld(int f) const {
@@ -128,31 +131,56 @@ struct Pipe {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
-// Consume the current chunk (32 fragments) in four quarters.  `step(ic<I>, w)` issues the MFMA of fragment I.
-// Fragment i of the NEXT quarter is read from LDS right before the MFMA of fragment i of the current one, so
-// every ds_read_b128 has eight MFMAs (256 cycles) to return; the issue order is pinned (the scheduler otherwise
-// sinks the reads next to their uses).  On entry w0 holds fragments 0..7 of the chunk; on exit w0 holds
-// fragments 0..7 of the next chunk.
-template <int Q, class Step>
-__device__ __forceinline__ void quarter(Pipe& p, bf16x8 (&cur)[8], bf16x8 (&nxt)[8], Step&& step) {
-    static_for<8>([&](auto ic) {
+// Consume the current chunk (32 fragments) in eight groups of kGrp = 4.  `step(ic<I>, w)` issues the MFMA of
+// fragment I.  Fragment i of the NEXT group is read from LDS right before the MFMA of fragment i of the current
+// one, so every ds_read_b128 has four MFMAs (128 cycles) to return and only 2 x 4 fragment registers are live;
+// the issue order is pinned (the scheduler otherwise sinks the reads next to their uses).  One LDS-DMA piece is
+// issued per group.  On entry w0 holds fragments 0..3 of the chunk; on exit w0 holds fragments 0..3 of the next.
+constexpr int kGrp = 4;
+template <int G, class P, class Step>
+__device__ __forceinline__ void group(P& p, bf16x8 (&cur)[kGrp], bf16x8 (&nxt)[kGrp], Step&& step) {
+    static_for<kGrp>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        nxt[i] = p.ld(((Q + 1) & 3) * 8 + i);
-        step(std::integral_constant<int, Q * 8 + i>{}, cur[i]);
-        if constexpr (i == 1) p.template piece<(2 * Q + 2) & 7>();
-        if constexpr (i == 5) p.template piece<(2 * Q + 3) & 7>();
+        nxt[i] = p.ld(((G + 1) & 7) * kGrp + i);
+        step(std::integral_constant<int, G * kGrp + i>{}, cur[i]);
+        if constexpr (i == 1) p.template piece<(G + 2) & 7>();
         PIN();
     });
 }
-template <class Step>
-__device__ __forceinline__ void consume_chunk(Pipe& p, bf16x8 (&w0)[8], bf16x8 (&w1)[8], Step&& step) {
-    quarter<0>(p, w0, w1, step);  // pieces 2, 3
-    quarter<1>(p, w1, w0, step);  // pieces 4, 5
-    quarter<2>(p, w0, w1, step);  // pieces 6, 7 -> the request moves on to the next chunk
-    p.sync();
+template <class P, class Step>
+__device__ __forceinline__ void consume_chunk(P& p, bf16x8 (&w0)[kGrp], bf16x8 (&w1)[kGrp], Step&& step) {
+    group<0>(p, w0, w1, step);  // piece 2
+    group<1>(p, w1, w0, step);
+    group<2>(p, w0, w1, step);
+    group<3>(p, w1, w0, step);
+    group<4>(p, w0, w1, step);
+    group<5>(p, w1, w0, step);  // piece 7 -> the request moves on to the next chunk
+    p.sync();                   // chunk m+1 complete everywhere; chunk m-1's buffer is free for the next request
     PIN();
-    p.rotate();                   // the last quarter prefetches fragments 0..7 of the next chunk
-    quarter<3>(p, w1, w0, step);  // pieces 0, 1 of the new request
+    group<6>(p, w0, w1, step);  // piece 0 of the new request
+    p.rotate();                 // the last group prefetches fragments 0..3 of the next chunk
+    group<7>(p, w1, w0, step);  // piece 1
+}
+
+// LDS rows (biases, staged emb row) are read through ONE opaque 32-bit LDS address per layer plus immediate offsets.
+// Left to itself the compiler materialises a separate address register per 32-feature tile, hoists all of them
+// out of the tile loop and spills them; each reload then waits on vmcnt(0), i.e. on every weight DMA in flight.
+typedef __attribute__((address_space(3))) const float lds_f;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x4_t lds_f4;
+__device__ __forceinline__ unsigned lds_base(const float* p) {
+    unsigned off = (unsigned)(uintptr_t)(lds_f*)p;
+    asm volatile("" : "+v"(off));
+    return off;
+}
+__device__ __forceinline__ f32x16 load16_lds(unsigned base, int elem) {  // base + 4 (elem + {0..3, 8..11, 16..19, 24..27})
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4_t t = *(lds_f4*)(uintptr_t)(base + 4u * (unsigned)(elem + 8 * q));
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    return v;
 }
 
 __device__ __forceinline__ f32x16 load16(const float* p) {  // p + {0..3, 8..11, 16..19, 24..27}
@@ -185,36 +213,57 @@ __device__ __forceinline__ void pack_out(const f32x16& v, bf16x8& lo, bf16x8& hi
 // all NT accumulators (AGPRs) advance together and one activation fragment feeds NT MFMAs.  In the LAST k-step
 // each MFMA writes a fresh register tile whose epilogue (ReLU, cvt to bf16, in-place store into the activation
 // array) is issued one MFMA later, and the accumulator is reloaded with the next layer's bias.
-template <int KS, int NT, int CHUNKS, bool RELU, int NT_NEXT, int NIN, int NOUT, int NACC>
-__device__ __forceinline__ void dense(Pipe& p, bf16x8 (&w0)[8], bf16x8 (&w1)[8], const bf16x8 (&Xin)[NIN], bf16x8 (&Xout)[NOUT],
+template <int KS, int NT, int CHUNKS, bool RELU, int NT_NEXT, class PIPE, int NIN, int NOUT, int NACC>
+__device__ __forceinline__ void dense(PIPE& p, bf16x8 (&w0)[kGrp], bf16x8 (&w1)[kGrp], const bf16x8 (&Xin)[NIN], bf16x8 (&Xout)[NOUT],
                                       f32x16 (&acc)[NACC], const float* next_bias, int hh) {
+    const unsigned nb = lds_base(next_bias + 4 * hh);
     // epilogue of one finished tile: ReLU, cvt to bf16 into the activation array, accumulator <- next bias
     auto finish = [&](auto tc) {
         constexpr int nt = decltype(tc)::value;
         pack_out<RELU>(acc[nt], Xout[2 * nt], Xout[2 * nt + 1]);
-        if constexpr (nt < NT_NEXT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
+        if constexpr (nt < NT_NEXT) acc[nt] = load16_lds(nb, 32 * nt);
     };
     static_for<CHUNKS>([&](auto cc) {
         consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) {
             constexpr int g = decltype(cc)::value * kChunkFrags + decltype(ic)::value, ks = g / NT, nt = g % NT;
             if constexpr (ks < KS) acc[nt] = MFMA(w, Xin[ks], acc[nt]);
             if constexpr (ks == KS - 1) {  // last k-step: finish the tile issued two MFMAs ago
-                if (p.exp & 4) return;
+                if (p.exp() & 4) return;
                 if constexpr (nt >= 2) finish(std::integral_constant<int, nt - 2>{});
             }
         });
     });
-    if (!(p.exp & 4)) {
+    if (!(p.exp() & 4)) {
         if constexpr (NT >= 2) finish(std::integral_constant<int, NT - 2>{});
+        PIN();
         finish(std::integral_constant<int, NT - 1>{});
+        PIN();
     }
-    static_for<NT_NEXT>([&](auto ic) {
+    static_for<NT_NEXT>([&](auto ic) {  // one tile at a time: 16 LDS reads, 16 accumulator writes, not 16 x that in flight
         constexpr int nt = decltype(ic)::value;
-        if constexpr (nt >= NT) acc[nt] = load16(next_bias + 32 * nt + 4 * hh);
+        if constexpr (nt >= NT) {
+            acc[nt] = load16_lds(nb, 32 * nt);
+            PIN();
+        }
     });
 }
 
-template <int H, int DT, bool STAMP = false>
+// One 1-KiB LDS-DMA transfer outside the weight pipeline (next tile's records / time-embedding row): 64 lanes x 16 B
+// from `gp` (per lane) to LDS byte offset `dst` + lane * 16.  Counted by vmcnt in issue order like the weight pieces.
+__device__ __forceinline__ void dma16(const void* gp, unsigned dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gp), "s"(d)
+                 : "memory");
+}
+
+// MODE 0: denoiser forward (per-lane global loads of the record and of emb[t]).
+// MODE 1: Tartan-Federer score.  Tiles never straddle a timestep, so t is tile-uniform: the tile's records
+//         (a contiguous block of x, <= 128 x x_ld floats) and its emb[t] + bias row are brought into LDS by DMA during
+//         the previous tile's last hidden layer — no per-tile global load ever lands in a VGPR.
+template <int H, int DT, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
     constexpr int KSH = H / 16;   // k-steps of a hidden activation
@@ -222,12 +271,15 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     constexpr int HA = NTH - 4;   // first of the four accumulators the head uses (split-K)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // LDS after the chunk buffers: biases (+H zeros), the Tartan-Federer noise table, per-timestep (a, b)
+    // LDS after the chunk buffers: biases (+H zeros), the Tartan-Federer noise table, per-timestep (a, b),
+    // the tile's emb row and the tile's records (MODE 1)
     float* sbias = reinterpret_cast<float*>(mtk_smem_f + kBufs * kChunkBytes);
     float* snoise = sbias + a.n_bias + H;
     float2* scoef = reinterpret_cast<float2*>(snoise + a.n_noise);
+    float* semb = reinterpret_cast<float*>(scoef + kMaxTF);
+    float* sx = semb + kDimT;
     for (int i = tid; i < a.n_bias + H; i += 256) sbias[i] = i < a.n_bias ? a.bias[i] : 0.0f;
-    if (a.mode == 1) {
+    if (MODE == 1) {
         for (int i = tid; i < a.n_noise; i += 256) snoise[i] = a.noise[i];
         for (int i = tid; i < kMaxTF; i += 256) {
             const SchedRow sr = a.sched[a.t_list[i] + a.add_t];
@@ -235,25 +287,43 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     }
 
-    Pipe p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, a.exp};
-    {
-        const int keep_exp = p.exp;
-        p.exp &= ~1;
-        p.fetch_all();  // chunk 0 -> buffer 0
-        p.fetch_all();  // chunk 1 -> buffer 1
-        p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
-        p.template piece<1>();
-        p.exp = keep_exp;
-    }
+    Pipe<true> p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, 0};
+    p.fetch_all();  // chunk 0 -> buffer 0
+    p.fetch_all();  // chunk 1 -> buffer 1
+    p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
+    p.template piece<1>();
+    p.exp_ = a.exp;
+
+    const int64_t n_tiles = (MODE == 1) ? a.tiles_per_k * a.nk : (a.rows + 127) / 128;
+    // MODE 1: DMA of tile `tile`'s records and emb row into LDS (all waves take part)
+    auto stage = [&](int64_t tile) {
+        if (MODE != 1 || tile >= n_tiles) return;
+        const int64_t k = tile / a.tiles_per_k;
+        const int64_t r0 = (tile - k * a.tiles_per_k) * 128;
+        const int64_t r1 = (r0 + 127 < a.BP - 1) ? r0 + 127 : a.BP - 1;
+        const int64_t rec0 = r0 / a.P;
+        const int bytes = (int)((r1 / a.P - rec0 + 1) * a.x_ld * 4);  // multiple of 16: x_ld % 4 == 0
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.x + rec0 * a.x_ld);
+        const unsigned sx_off = (unsigned)(reinterpret_cast<unsigned char*>(sx) - mtk_smem_f);
+        for (int q = wid; q * 1024 < bytes; q += 4)
+            if (q * 1024 + lane * 16 < bytes) dma16(src + q * 1024 + lane * 16, sx_off + q * 1024);
+        if (wid == 3 && lane < kDimT / 4) {
+            const int t = a.t_list[k];
+            dma16(reinterpret_cast<const unsigned char*>(a.embb + (int64_t)t * a.emb_ld) + lane * 16,
+                  (unsigned)(reinterpret_cast<unsigned char*>(semb) - mtk_smem_f));
+        }
+    };
+    stage(blockIdx.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // chunks 0, 1 and the LDS tables visible to every wave
-    bf16x8 w0[8], w1[8];
-    static_for<8>([&](auto ic) { w0[decltype(ic)::value] = p.ld(decltype(ic)::value); });
+    __syncthreads();  // chunks 0, 1, the first tile's inputs and the LDS tables visible to every wave
+    bf16x8 w0[kGrp], w1[kGrp];
+    static_for<kGrp>([&](auto ic) { w0[decltype(ic)::value] = p.ld(decltype(ic)::value); });
 
     f32x16 acc[NTH];
     bf16x8 X[KSH];
     unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int slot) {
+        PIN();  // phase boundary: keeps the scheduler from mixing the phases' register peaks (fewer spills)
         if constexpr (STAMP) {
             PIN();
             unsigned long long tnow;
@@ -264,71 +334,93 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     };
 
-    // ---- per-tile inputs are requested one tile ahead (a single wave per SIMD has nothing else to hide a
-    // ---- global-memory round trip behind): the timestep first, then the record and the emb[t] + bias rows
-    const int64_t n_tiles = (a.rows + 127) / 128;
-    struct Where { int64_t row; bool valid; int64_t xoff; int kk, pp; };
+    // ---- where a tile's lane sits
+    struct Where { int64_t row; bool valid; int64_t xoff; int kk, pp, rl; };
     auto locate = [&](int64_t tile) {
         Where w;
-        w.row = tile * 128 + wid * 32 + li;
-        w.valid = tile < n_tiles && w.row < a.rows;
-        w.kk = 0; w.pp = 0;
-        if (a.mode == 0) {
+        w.kk = 0; w.pp = 0; w.rl = 0; w.xoff = 0;
+        if (MODE == 0) {
+            w.row = tile * 128 + wid * 32 + li;
+            w.valid = tile < n_tiles && w.row < a.rows;
             w.xoff = w.row * a.x_rs;
         } else {
-            const int64_t k = w.valid ? w.row / a.BP : 0;
-            const int64_t rr = w.row - k * a.BP;
+            const int64_t k = tile / a.tiles_per_k;
+            const int64_t r0 = (tile - k * a.tiles_per_k) * 128;
+            const int64_t rr = r0 + wid * 32 + li;
+            w.valid = tile < n_tiles && rr < a.BP;
             const int64_t rec = rr / a.P;
             w.kk = (int)k;
             w.pp = (int)(rr - rec * a.P);
-            w.xoff = rec * a.x_ld;
+            w.rl = (int)(rec - r0 / a.P);  // record index inside the staged block
+            w.row = k * a.BP + rr;
         }
         return w;
     };
+    // ---- MODE 0: per-tile inputs are requested one tile ahead (a single wave per SIMD has nothing else to hide a
+    // ---- global-memory round trip behind): the timestep first, then the record and the emb[t] + bias rows
     auto request_t = [&](const Where& w) -> int {
-        if (a.mode == 0) return a.tvec ? (w.valid ? (int)a.tvec[w.row] : 0) : a.t_scalar;
-        return a.t_list[w.kk];
+        return a.tvec ? (w.valid ? (int)a.tvec[w.row] : 0) : a.t_scalar;
     };
-    float raw[KS0 * 8];
+    float raw[MODE == 0 ? KS0 * 8 : 1];
     auto request_x = [&](const Where& w) {
-        const int64_t cs = (a.mode == 0) ? a.x_cs : 1;
-        static_for<KS0>([&](auto ic) {
-            constexpr int ks = decltype(ic)::value;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int f = feat(ks, hh, j);
-                raw[ks * 8 + j] = (w.valid && f < a.D) ? a.x[w.xoff + (int64_t)f * cs] : 0.0f;
-            }
-        });
-    };
-    auto request_emb = [&](int t) {  // proj accumulators <- emb[t] + proj bias (MODEL:614), straight from the table
-        const float* er = a.embb + (int64_t)t * a.emb_ld;
-        static_for<kDimT / 32>([&](auto ic) { acc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value + 4 * hh); });
-    };
-
-    Where cur = locate(blockIdx.x);
-    int t_cur = request_t(cur);
-    request_x(cur);
-    request_emb(t_cur);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        stamp(-1);
-        // ---- input fragments: bf16 of x (mode 0) or of x_t = a x + b noise_p (mode 1, GMD:302 / TF:86)
-        bf16x8 XI[KS0];
-        {
-            const float2 ab = (a.mode == 1) ? scoef[cur.kk] : make_float2(1.0f, 0.0f);
+        if constexpr (MODE == 0) {
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f = feat(ks, hh, j);
-                    float v = raw[ks * 8 + j];
-                    if (a.mode == 1) v = (cur.valid && f < a.D) ? ab.x * v + ab.y * snoise[cur.pp * a.D + f] : 0.0f;
-                    XI[ks][j] = (__bf16)v;
+                    raw[ks * 8 + j] = (w.valid && f < a.D) ? a.x[w.xoff + (int64_t)f * a.x_cs] : 0.0f;
                 }
             });
         }
+    };
+    auto request_emb = [&](int t) {  // proj accumulators <- emb[t] + proj bias (MODE:614), straight from the table
+        const float* er = a.embb + (int64_t)t * a.emb_ld;
+        static_for<kDimT / 32>([&](auto ic) {
+            acc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value + 4 * hh);
+            PIN();
+        });
+    };
+
+    Where cur = locate(blockIdx.x);
+    int t_cur = 0;
+    if constexpr (MODE == 0) {
+        t_cur = request_t(cur);
+        request_x(cur);
+        request_emb(t_cur);
+    }
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        stamp(-1);
+        // ---- input fragments: bf16 of x (MODE 0) or of x_t = a x + b noise_p (MODE 1, GMD:302 / TF:86)
+        bf16x8 XI[KS0];
+        if constexpr (MODE == 0) {
+            static_for<KS0>([&](auto ic) {
+                constexpr int ks = decltype(ic)::value;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) XI[ks][j] = (__bf16)raw[ks * 8 + j];
+            });
+        } else {
+            const float2 ab = scoef[cur.kk];
+            const float* xr = sx + cur.rl * (int)a.x_ld;
+            const float* nr = snoise + cur.pp * a.D;
+            static_for<KS0>([&](auto ic) {
+                constexpr int ks = decltype(ic)::value;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = feat(ks, hh, j);
+                    const float v = (cur.valid && f < a.D) ? ab.x * xr[f] + ab.y * nr[f] : 0.0f;
+                    XI[ks][j] = (__bf16)v;
+                }
+            });
+            const unsigned eb = lds_base(semb + 4 * hh);
+            static_for<kDimT / 32>([&](auto ic) {  // proj accumulators <- emb[t] + proj bias, from the staged row
+                acc[decltype(ic)::value] = load16_lds(eb, 32 * decltype(ic)::value);
+                PIN();
+            });
+        }
         const Where nxt = locate(tile + gridDim.x);
-        const int t_nxt = request_t(nxt);
+        int t_nxt = 0;
+        if constexpr (MODE == 0) t_nxt = request_t(nxt);
         const float* sb = sbias + kDimT;
         stamp(0);  // prologue
         // ---- proj (D -> 128)
@@ -337,21 +429,25 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         // ---- hidden layers (MODEL:300-301); activations are rewritten in place
         sb += H;
         stamp(1);  // proj
+        if (a.n_hidden == 1) stage(tile + gridDim.x);
         dense<kDimT / 16, NTH, NTH*(kDimT / 16) / kChunkFrags, true, NTH>(p, w0, w1, XP, X, acc, sb, hh);
         stamp(2);  // 128 -> H
         for (int l = 1; l < a.n_hidden; ++l) {
             sb += H;
+            if (l == a.n_hidden - 1) stage(tile + gridDim.x);  // lands (and is fenced by the chunk barriers) before the head ends
             dense<KSH, NTH, NTH * KSH / kChunkFrags, true, NTH>(p, w0, w1, X, X, acc, sb, hh);
         }
         stamp(3);  // H -> H layers
-        // ---- head (H -> D), MODEL:303.  Only four accumulators are busy now: the next tile's record and its
+        // ---- head (H -> D), MODEL:303.  Only four accumulators are busy now: in MODE 0 the next tile's record and its
         // ---- emb rows are requested here and land (in the free accumulators) while the head runs.
-        request_x(nxt);
-        request_emb(t_nxt);
+        if constexpr (MODE == 0) {
+            request_x(nxt);
+            request_emb(t_nxt);
+        }
         float sq = 0.0f;
         static_for<DT>([&](auto tc) {
             constexpr int nt = decltype(tc)::value;
-            acc[HA] = load16(sb + 32 * nt + 4 * hh);
+            acc[HA] = load16_lds(lds_base(sb + 4 * hh), 32 * nt);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[HA + 1][r] = acc[HA + 2][r] = acc[HA + 3][r] = 0.0f;
             // four independent accumulation chains over k (a single chain would wait out the MFMA latency)
@@ -362,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = (acc[HA][r] + acc[HA + 1][r]) + (acc[HA + 2][r] + acc[HA + 3][r]);
-            if (a.mode == 0) {
+            if constexpr (MODE == 0) {
                 if (cur.valid) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -381,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                 }
             }
         });
-        if (a.mode == 1) {  // TF:92-95: mean over the numeric features
+        if constexpr (MODE == 1) {  // TF:92-95: mean over the numeric features
             sq += __shfl_xor(sq, 32);
             if (cur.valid && hh == 0) a.score[cur.row] = sq / (float)a.D;
         }
@@ -390,6 +486,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         stamp(4);  // head + output
         if constexpr (STAMP) st_sum[5] += 1;
     }
+    (void)t_cur;
     if constexpr (STAMP) {
         if (lane == 0 && wid == 0)
             for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_sum[i]);
@@ -442,13 +539,15 @@ bool layout_for(const mtk_ctx* c, Layout& L) {
     return true;
 }
 
-template <int H>
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <int H, int MODE>
 int launch(const Layout& L, const FusedArgs& a, int grid, size_t lds, hipStream_t s) {
     switch (L.DT) {
-        case 1: hipLaunchKernelGGL((k_fused<H, 1>), dim3(grid), dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((k_fused<H, 2>), dim3(grid), dim3(256), lds, s, a); break;
-        case 3: hipLaunchKernelGGL((k_fused<H, 3>), dim3(grid), dim3(256), lds, s, a); break;
-        case 4: hipLaunchKernelGGL((k_fused<H, 4>), dim3(grid), dim3(256), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((k_fused<H, 1, MODE>), dim3(grid), dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((k_fused<H, 2, MODE>), dim3(grid), dim3(256), lds, s, a); break;
+        case 3: hipLaunchKernelGGL((k_fused<H, 3, MODE>), dim3(grid), dim3(256), lds, s, a); break;
+        case 4: hipLaunchKernelGGL((k_fused<H, 4, MODE>), dim3(grid), dim3(256), lds, s, a); break;
         default: MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused denoiser: D tiles = %d", L.DT);
     }
     MTK_HIP(hipGetLastError());
@@ -464,6 +563,12 @@ int n_cus(int device) {
     return n;
 }
 
+// bytes of LDS a launch needs: chunk buffers, biases (+H zeros), noise table, (a, b) per timestep, emb row, records
+size_t lds_need(const Layout& L, const FusedArgs& a) {
+    const size_t floats = (size_t)L.n_bias + L.H + a.n_noise + 2 * kMaxTF + kDimT + (a.mode == 1 ? 128 * (size_t)a.x_ld : 0);
+    return kBufs * kChunkBytes + ((floats * 4 + 15) & ~(size_t)15);
+}
+
 int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     Layout L;
     if (!layout_for(c, L)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused denoiser: unsupported shape");
@@ -472,27 +577,27 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     a.n_bias = L.n_bias;
     a.embb = c->d_embb;
     a.n_noise = (a.mode == 1) ? a.P * c->D : 0;
-    if (a.n_noise > kMaxNoise) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused Tartan-Federer kernel: P * Nn = %d exceeds %d", a.n_noise, kMaxNoise);
     a.emb_ld = c->emb_ld;
     a.n_hidden = L.n_hidden;
     a.total_chunks = L.total_chunks;
     a.D = c->D;
     static const int exp_env = getenv("MTK_FUSED_EXP") ? atoi(getenv("MTK_FUSED_EXP")) : 0;
     a.exp = exp_env;
-    const int64_t tiles = (a.rows + 127) / 128;
+    const int64_t tiles = (a.mode == 1) ? a.tiles_per_k * a.nk : (a.rows + 127) / 128;
     const int cus = n_cus(c->device);
     const int grid = (int)(tiles < cus ? tiles : cus);
+    const size_t lds = lds_need(L, a);
+    if (lds > kMaxLds) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused kernel: %zu bytes of LDS needed, %zu available", lds, kMaxLds);
     static const bool stamps_env = getenv("MTK_FUSED_STAMPS") != nullptr;
-    if (stamps_env && L.DT == 1) {
+    if (stamps_env && L.DT == 1 && a.mode == 1) {
         static unsigned long long* d_st = nullptr;
         if (!d_st) {
             MTK_HIP(hipMalloc(&d_st, 64));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBufs * kChunkBytes + 32 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         }
         MTK_HIP(hipMemsetAsync(d_st, 0, 64, s));
         a.stamps = d_st;
-        const size_t lds2 = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H + a.n_noise + 2 * kMaxTF) * 4 + 15) & ~(size_t)15);
-        hipLaunchKernelGGL((k_fused<512, 1, true>), dim3(grid), dim3(256), lds2, s, a);
+        hipLaunchKernelGGL((k_fused<512, 1, 1, true>), dim3(grid), dim3(256), lds, s, a);
         MTK_HIP(hipStreamSynchronize(s));
         unsigned long long h[8];
         MTK_HIP(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
@@ -501,8 +606,17 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
                 h[2] / n, h[3] / n, h[4] / n);
         return MTK_OK;
     }
-    const size_t lds = kBufs * kChunkBytes + (((size_t)(L.n_bias + L.H + a.n_noise + 2 * kMaxTF) * 4 + 15) & ~(size_t)15);
-    return launch<512>(L, a, grid, lds, s);
+    return a.mode == 1 ? launch<512, 1>(L, a, grid, lds, s) : launch<512, 0>(L, a, grid, lds, s);
+}
+
+// [rows][cols] strided -> compact [rows][ld] (zero padded): the fused Tartan-Federer kernel stages records by 16-byte DMA
+__global__ void k_compact_rows(float* dst, int ld, const float* src, int64_t src_ld, int64_t rows, int cols) {
+    const int64_t n = rows * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int cidx = (int)(i - r * ld);
+        dst[i] = cidx < cols ? src[r * src_ld + cidx] : 0.0f;
+    }
 }
 
 }  // namespace
@@ -511,6 +625,9 @@ void mtk_free_fused(mtk_ctx* c) {
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_bias_all) (void)hipFree(c->d_bias_all);
     if (c->d_embb) (void)hipFree(c->d_embb);
+    if (c->tf_pack) (void)hipFree(c->tf_pack);
+    c->tf_pack = nullptr;
+    c->tf_pack_elems = 0;
     c->d_embb = nullptr;
     c->d_wfrag = nullptr;
     c->d_bias_all = nullptr;
@@ -527,11 +644,13 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
     if (!layout_for(c, L)) return MTK_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        const int max_lds = kBufs * kChunkBytes + 32 * 1024;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        const int max_lds = (int)kMaxLds;
+        const void* fns[] = {
+            reinterpret_cast<const void*>(k_fused<512, 1, 0>), reinterpret_cast<const void*>(k_fused<512, 2, 0>),
+            reinterpret_cast<const void*>(k_fused<512, 3, 0>), reinterpret_cast<const void*>(k_fused<512, 4, 0>),
+            reinterpret_cast<const void*>(k_fused<512, 1, 1>), reinterpret_cast<const void*>(k_fused<512, 2, 1>),
+            reinterpret_cast<const void*>(k_fused<512, 3, 1>), reinterpret_cast<const void*>(k_fused<512, 4, 1>)};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         attr_set = true;
     }
     c->wfrag_bytes = (size_t)L.total_chunks * kChunkBytes;
@@ -578,16 +697,49 @@ int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64
     return run(c, a, s);
 }
 
+// Returns MTK_ERR_UNSUPPORTED (without setting up anything) when the staged-record layout cannot hold this shape:
+// the caller then runs noising / denoiser / MSE as three kernels.
 int mtk_fused_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_t x_ld, const float* noise, int n_t,
                        const int32_t* t_list_host, int add_t, float* score, hipStream_t s) {
+    Layout L;
+    if (!layout_for(c, L)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused denoiser: unsupported shape");
+    if ((int64_t)P * c->D > kMaxNoise) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused Tartan-Federer kernel: P * Nn = %lld exceeds %d", (long long)P * c->D, kMaxNoise);
+    // records are staged in LDS by 16-byte DMA: compact, 16-byte aligned rows of a multiple of 4 floats
+    const int ld = (c->D + 3) & ~3;
+    {
+        FusedArgs probe{};
+        probe.mode = 1;
+        probe.x_ld = ld;
+        probe.n_noise = P * c->D;
+        if (lds_need(L, probe) > kMaxLds) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused Tartan-Federer kernel: records of %d features do not fit the LDS staging area", c->D);
+    }
+    const float* xs = x;
+    int64_t xs_ld = x_ld;
+    if (x_ld != ld || (reinterpret_cast<uintptr_t>(x) & 15)) {
+        const size_t need = (size_t)B * ld;
+        if (need > c->tf_pack_elems) {
+            MTK_HIP(hipStreamSynchronize(s));
+            if (c->tf_pack) (void)hipFree(c->tf_pack);
+            c->tf_pack = nullptr;
+            c->tf_pack_elems = 0;
+            MTK_HIP(hipMalloc(&c->tf_pack, sizeof(float) * need));
+            c->tf_pack_elems = need;
+        }
+        hipLaunchKernelGGL(k_compact_rows, dim3(1024), dim3(256), 0, s, c->tf_pack, ld, x, x_ld, B, c->D);
+        MTK_HIP(hipGetLastError());
+        xs = c->tf_pack;
+        xs_ld = ld;
+    }
     for (int k0 = 0; k0 < n_t; k0 += kMaxTF) {
         const int nk = (n_t - k0 < kMaxTF) ? n_t - k0 : kMaxTF;
         FusedArgs a{};
         a.mode = 1;
         a.BP = B * P;
         a.P = P;
+        a.nk = nk;
+        a.tiles_per_k = (a.BP + 127) / 128;
         a.rows = a.BP * nk;
-        a.x = x; a.x_ld = x_ld;
+        a.x = xs; a.x_ld = xs_ld;
         a.noise = noise;
         a.score = score + (int64_t)k0 * a.BP;
         a.sched = c->d_rows;

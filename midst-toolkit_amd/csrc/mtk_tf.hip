@@ -60,9 +60,13 @@ extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_
     hipStream_t s = (hipStream_t)stream;
     if (precision == MTK_PREC_BF16) {
         if (!c->fused_ok) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: the fused bf16 kernel does not support this denoiser shape");
-        return mtk_fused_tf_score(c, B, P, x, x_ld, noise, n_t, t_list_host, add_t, score, s);
+        const int rc = mtk_fused_tf_score(c, B, P, x, x_ld, noise, n_t, t_list_host, add_t, score, s);
+        // wide records / large noise tables do not fit the fused kernel's LDS staging: same arithmetic as three kernels
+        // (noising, bf16 MFMA denoiser, MSE) below
+        if (rc != MTK_ERR_UNSUPPORTED) return rc;
+    } else if (precision != MTK_PREC_FP32) {
+        MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: unknown precision %d", precision);
     }
-    if (precision != MTK_PREC_FP32) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: unknown precision %d", precision);
 
     const int Nn = c->Nn;
     const int64_t rec_chunk = (1 << 20) / P > 0 ? (1 << 20) / P : 1;  // <= 1M rows per pass
@@ -85,7 +89,7 @@ extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_
             hipLaunchKernelGGL(k_tf_noise, dim3(grid_for(rows * Nn)), dim3(256), 0, s, rows, P, Nn, x + r0 * x_ld, x_ld, noise, a, b,
                                c->tf_ws[0]);
             MTK_HIP(hipGetLastError());
-            int rc = mtk_mlp_forward(c, rows, c->tf_ws[0], Nn, 1, nullptr, t, c->tf_ws[1], Nn, 1, MTK_PREC_FP32, stream);
+            int rc = mtk_mlp_forward(c, rows, c->tf_ws[0], Nn, 1, nullptr, t, c->tf_ws[1], Nn, 1, precision, stream);
             if (rc) return rc;
             hipLaunchKernelGGL(k_tf_mse, dim3(grid_for(rows)), dim3(256), 0, s, rows, P, Nn, c->tf_ws[1], noise,
                                score + ((int64_t)k * B + r0) * P);
