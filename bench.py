@@ -130,7 +130,7 @@ def main():
 
     # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same configuration
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r1_pmc_fused.json")
+    pmc = os.path.join(ROOT, "benchmarks", "pmc_fused.json")  # copy of profiles/r1_pmc_fused.json that travels to the GPU box
     if a.precision == "bf16" and a.records == 100_000 and a.nt == 10 and a.hidden == 512 and os.path.exists(pmc):
         with open(pmc) as f:
             rec = json.load(f)

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtk_hip.so")
+LIB_PATH = os.environ.get("MTK_LIB_PATH") or os.path.join(_HERE, "libmtk_hip.so")  # override: A/B builds of the same ABI
 
 MTK_OK, MTK_ERR_ARG, MTK_ERR_UNSUPPORTED, MTK_ERR_HIP, MTK_ERR_STATE = 0, -1, -2, -3, -4
 PREC_FP32, PREC_BF16 = 0, 1
