@@ -364,12 +364,30 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     float raw[MODE == 0 ? KS0 * 8 : 1];
     auto request_x = [&](const Where& w) {
         if constexpr (MODE == 0) {
+            // Branch-free (every load is issued, clamped to a valid address, and masked afterwards) and with the lane
+            // half, D and the column stride made opaque per tile: left visible, the 8 KS0 clamped feature indices,
+            // their 64-bit offsets and their `f < D` masks are loop invariants that get hoisted out of the tile loop and
+            // spilled (VGPRs and SGPRs), and each reload waits on every weight DMA in flight.
+            int hq = hh, Dq = a.D;
+            int64_t xcs = a.x_cs;
+            asm volatile("" : "+v"(hq), "+s"(Dq), "+s"(xcs));
+            const int64_t base = w.valid ? w.xoff : 0;
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int f = feat(ks, hh, j);
-                    raw[ks * 8 + j] = (w.valid && f < a.D) ? a.x[w.xoff + (int64_t)f * a.x_cs] : 0.0f;
+                    const int f = feat(ks, hq, j);
+                    const int fc = f < Dq ? f : Dq - 1;
+                    raw[ks * 8 + j] = a.x[base + (int64_t)fc * xcs];
+                }
+            });
+            asm volatile("" ::: "memory");  // the loads stay above this line, unconditional; the masks below cannot pull them down
+            static_for<KS0>([&](auto ic) {
+                constexpr int ks = decltype(ic)::value;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = feat(ks, hq, j);
+                    raw[ks * 8 + j] = (w.valid && f < Dq) ? raw[ks * 8 + j] : 0.0f;
                 }
             });
         }
@@ -386,14 +404,17 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     int t_cur = 0;
     if constexpr (MODE == 0) {
         t_cur = request_t(cur);
-        request_x(cur);
-        request_emb(t_cur);
     }
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         stamp(-1);
         // ---- input fragments: bf16 of x (MODE 0) or of x_t = a x + b noise_p (MODE 1, GMD:302 / TF:86)
         bf16x8 XI[KS0];
         if constexpr (MODE == 0) {
+            // the record and its emb[t] + bias rows are loaded HERE, not a tile ahead: at this point the activation
+            // registers of the previous tile are dead, so the 8 KS0 + 64 values in flight cost no spills; only the
+            // timestep (one register) is requested a tile ahead.  One exposed global round trip per 128-row tile.
+            request_x(cur);
+            request_emb(t_cur);
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
@@ -440,10 +461,6 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         stamp(3);  // H -> H layers
         // ---- head (H -> D), MODEL:303.  Only four accumulators are busy now: in MODE 0 the next tile's record and its
         // ---- emb rows are requested here and land (in the free accumulators) while the head runs.
-        if constexpr (MODE == 0) {
-            request_x(nxt);
-            request_emb(t_nxt);
-        }
         float sq = 0.0f;
         static_for<DT>([&](auto tc) {
             constexpr int nt = decltype(tc)::value;
@@ -460,10 +477,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             for (int r = 0; r < 16; ++r) o[r] = (acc[HA][r] + acc[HA + 1][r]) + (acc[HA + 2][r] + acc[HA + 3][r]);
             if constexpr (MODE == 0) {
                 if (cur.valid) {
+                    int64_t ocs = a.o_cs;  // opaque for the same reason as in request_x
+                    int hq = hh, Dq = a.D;
+                    asm volatile("" : "+s"(ocs), "+v"(hq), "+s"(Dq));
+                    float* orow = a.out + cur.row * a.o_rs;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int f = 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
-                        if (f < a.D) a.out[cur.row * a.o_rs + (int64_t)f * a.o_cs] = o[r];
+                        const int f = 32 * nt + 8 * (r >> 2) + 4 * hq + (r & 3);
+                        if (f < Dq) orow[(int64_t)f * ocs] = o[r];
                     }
                 }
             } else {
