@@ -298,11 +298,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     // MODE 1: DMA of tile `tile`'s records and emb row into LDS (all waves take part)
     auto stage = [&](int64_t tile) {
         if (MODE != 1 || tile >= n_tiles) return;
-        const int64_t k = tile / a.tiles_per_k;
-        const int64_t r0 = (tile - k * a.tiles_per_k) * 128;
-        const int64_t r1 = (r0 + 127 < a.BP - 1) ? r0 + 127 : a.BP - 1;
-        const int64_t rec0 = r0 / a.P;
-        const int bytes = (int)((r1 / a.P - rec0 + 1) * a.x_ld * 4);  // multiple of 16: x_ld % 4 == 0
+        const unsigned tpk = (unsigned)a.tiles_per_k, P = (unsigned)a.P, BP = (unsigned)a.BP;
+        const unsigned k = (unsigned)tile / tpk;
+        const unsigned r0 = ((unsigned)tile - k * tpk) * 128u;
+        const unsigned r1 = (r0 + 127u < BP - 1u) ? r0 + 127u : BP - 1u;
+        const int64_t rec0 = (P == 1) ? r0 : r0 / P;
+        const int bytes = (int)((((P == 1) ? r1 : r1 / P) - rec0 + 1) * a.x_ld * 4);  // multiple of 16: x_ld % 4 == 0
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a.x + rec0 * a.x_ld);
         const unsigned sx_off = (unsigned)(reinterpret_cast<unsigned char*>(sx) - mtk_smem_f);
         for (int q = wid; q * 1024 < bytes; q += 4)
@@ -343,16 +344,17 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             w.row = tile * 128 + wid * 32 + li;
             w.valid = tile < n_tiles && w.row < a.rows;
             w.xoff = w.row * a.x_rs;
-        } else {
-            const int64_t k = tile / a.tiles_per_k;
-            const int64_t r0 = (tile - k * a.tiles_per_k) * 128;
-            const int64_t rr = r0 + wid * 32 + li;
-            w.valid = tile < n_tiles && rr < a.BP;
-            const int64_t rec = rr / a.P;
+        } else {  // 32-bit arithmetic (the host checks BP * P and the tile count fit): 64-bit divisions cost hundreds of cycles
+            const unsigned tpk = (unsigned)a.tiles_per_k, P = (unsigned)a.P, BP = (unsigned)a.BP;
+            const unsigned k = (unsigned)tile / tpk;
+            const unsigned r0 = ((unsigned)tile - k * tpk) * 128u;
+            const unsigned rr = r0 + (unsigned)(wid * 32 + li);
+            w.valid = tile < n_tiles && rr < BP;
+            const unsigned rec = (P == 1) ? rr : rr / P;
             w.kk = (int)k;
-            w.pp = (int)(rr - rec * a.P);
-            w.rl = (int)(rec - r0 / a.P);  // record index inside the staged block
-            w.row = k * a.BP + rr;
+            w.pp = (int)(rr - rec * P);
+            w.rl = (int)(rec - ((P == 1) ? r0 : r0 / P));  // record index inside the staged block
+            w.row = (int64_t)k * a.BP + rr;
         }
         return w;
     };
@@ -422,14 +424,16 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             });
         } else {
             const float2 ab = scoef[cur.kk];
+            int hq = hh, Dq = a.D;  // opaque per tile, see request_x
+            asm volatile("" : "+v"(hq), "+s"(Dq));
             const float* xr = sx + cur.rl * (int)a.x_ld;
-            const float* nr = snoise + cur.pp * a.D;
+            const float* nr = snoise + cur.pp * Dq;
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int f = feat(ks, hh, j);
-                    const float v = (cur.valid && f < a.D) ? ab.x * xr[f] + ab.y * nr[f] : 0.0f;
+                    const int f = feat(ks, hq, j);
+                    const float v = (cur.valid && f < Dq) ? ab.x * xr[f] + ab.y * nr[f] : 0.0f;
                     XI[ks][j] = (__bf16)v;
                 }
             });
@@ -488,11 +492,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                     }
                 }
             } else {
+                int hq = hh, Dq = a.D;
+                asm volatile("" : "+v"(hq), "+s"(Dq));
+                const float* nr = snoise + cur.pp * Dq;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int f = 32 * nt + 8 * (r >> 2) + 4 * hh + (r & 3);
-                    if (f < a.D) {
-                        const float d = snoise[cur.pp * a.D + f] - o[r];
+                    const int f = 32 * nt + 8 * (r >> 2) + 4 * hq + (r & 3);
+                    if (f < Dq) {
+                        const float d = nr[f] - o[r];
                         sq += d * d;
                     }
                 }
@@ -759,6 +766,7 @@ int mtk_fused_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_t x_l
         a.P = P;
         a.nk = nk;
         a.tiles_per_k = (a.BP + 127) / 128;
+        if (a.BP + 128 >= (int64_t)1 << 31 || a.tiles_per_k * nk >= (int64_t)1 << 31) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused Tartan-Federer kernel: B * P = %lld rows per timestep exceed 2^31", (long long)a.BP);
         a.rows = a.BP * nk;
         a.x = xs; a.x_ld = xs_ld;
         a.noise = noise;
