@@ -24,10 +24,8 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int TM = 128, TN = 128, TK = 32;
-constexpr int LDN = TK + 4;    // row-major tile in LDS: [128][36]
-constexpr int LDT = TM + 4;    // transposed tile in LDS: [32][132]
-constexpr int TILE_FLOATS = TM * LDN > TK * LDT ? TM * LDN : TK * LDT;
+constexpr int TM = 128, TN = 128, TK = 32;  // padding granules of the operands (the 64-wide tile variant divides them)
+constexpr int LDN = TK + 4;                 // row-major tile in LDS: [rows][36]
 
 struct G2 {
     int M, N, K;            // M and K are tile multiples; N is the number of columns stored (grid.y covers it)
@@ -35,7 +33,7 @@ struct G2 {
     const float* A; int64_t lda;   // AT ? A[k * lda + m] : A[m * lda + k]
     const float* B; int64_t ldb;   // BT ? B[k * ldb + n] : B[n * ldb + k]
     float* C; int64_t c_rs, c_cs;  // C[m * c_rs + n * c_cs]
-    const float* bias;             // [grid.y * 128] or null
+    const float* bias;             // [grid.y * tile] or null
     const float* emb; int emb_ld;  // optional [T][emb_ld], gathered by tvec[m]
     const int64_t* tvec; int64_t rows_valid;
     const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed where mask <= 0
@@ -43,84 +41,116 @@ struct G2 {
     int atomic;                    // accumulate with fp32 atomic add (split-K)
 };
 
-template <bool TR>
-__device__ __forceinline__ void load_tile(float* lds, const float* src, int64_t ld, int64_t r0, int k0, int tid) {
+// One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
+// the MFMAs that consume the previous block (software pipelining: at the batch sizes the reference trains with there
+// are too few workgroups per CU to hide a global round trip per k-block any other way).
+template <bool TR, int T>
+struct TileMover {
+    static constexpr int NLD = T * TK / 4 / 256;  // float4 per thread
+    static constexpr int LDT = T + 4;             // transposed tile in LDS: [32][T + 4]
+    float4 r[NLD];
+    __device__ __forceinline__ void load(const float* src, int64_t ld, int64_t r0, int k0, int tid) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = tid + 256 * q;
+            if (!TR) {
+                const int rr = idx >> 3, c = (idx & 7) * 4;
+                r[q] = *reinterpret_cast<const float4*>(src + (r0 + rr) * ld + k0 + c);
+            } else {
+                const int kk = idx / (T / 4), r4 = (idx % (T / 4)) * 4;
+                r[q] = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + kk) * ld + r0 + r4);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = tid + 256 * q;
+            if (!TR) {
+                const int rr = idx >> 3, c = (idx & 7) * 4;
+                *reinterpret_cast<float4*>(&lds[rr * LDN + c]) = r[q];
+            } else {
+                const int kk = idx / (T / 4), r4 = (idx % (T / 4)) * 4;
+                *reinterpret_cast<float4*>(&lds[kk * LDT + r4]) = r[q];
+            }
+        }
+    }
+    // lane (li, hh) takes k in [16 hh, 16 hh + 16) of the K block for both operands
+    static __device__ __forceinline__ void frag(const float* lds, int row, int hh, float (&f)[16]) {
         if (!TR) {
-            const int r = idx >> 3, c = (idx & 7) * 4;
-            *reinterpret_cast<float4*>(&lds[r * LDN + c]) = *reinterpret_cast<const float4*>(src + (r0 + r) * ld + k0 + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&lds[row * LDN + 16 * hh + 4 * q]);
+                f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+            }
         } else {
-            const int kk = idx >> 5, r4 = (idx & 31) * 4;
-            *reinterpret_cast<float4*>(&lds[kk * LDT + r4]) = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + kk) * ld + r0 + r4);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) f[s] = lds[(16 * hh + s) * LDT + row];
         }
     }
-}
-// lane (li, hh) takes k in [16 hh, 16 hh + 16) of the K block for both operands
-template <bool TR>
-__device__ __forceinline__ void fetch_frag(const float* lds, int row, int hh, float (&f)[16]) {
-    if (!TR) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(&lds[row * LDN + 16 * hh + 4 * q]);
-            f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) f[s] = lds[(16 * hh + s) * LDT + row];
-    }
-}
+};
 
-template <bool AT, bool BT>
+// WT = 2: 128 x 128 workgroup tile (each wave 2 x 2 MFMA tiles); WT = 1: 64 x 64 (each wave one 32 x 32 tile), used when
+// the larger tile would leave the chip with fewer than two workgroups per CU.
+template <bool AT, bool BT, int WT>
 __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
+    constexpr int T = 64 * WT;
+    constexpr int TILE_FLOATS = T * LDN > TK * (T + 4) ? T * LDN : TK * (T + 4);
     __shared__ __attribute__((aligned(16))) float As[TILE_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[TILE_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
+    const int64_t m0 = (int64_t)blockIdx.x * T;
+    const int n0 = blockIdx.y * T;
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
+    TileMover<AT, T> ma;
+    TileMover<BT, T> mb;
+    ma.load(g.A, g.lda, m0, kbeg, tid);
+    mb.load(g.B, g.ldb, n0, kbeg, tid);
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        load_tile<AT>(As, g.A, g.lda, m0, k0, tid);
-        load_tile<BT>(Bs, g.B, g.ldb, n0, k0, tid);
+        ma.store(As, tid);
+        mb.store(Bs, tid);
         __syncthreads();
-        float a[2][16], b[2][16];
+        if (k0 + TK < kend) {  // next k-block's global loads fly while this one is multiplied
+            ma.load(g.A, g.lda, m0, k0 + TK, tid);
+            mb.load(g.B, g.ldb, n0, k0 + TK, tid);
+        }
+        float a[WT][16], b[WT][16];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) fetch_frag<AT>(As, wr * 64 + mt * 32 + li, hh, a[mt]);
+        for (int mt = 0; mt < WT; ++mt) TileMover<AT, T>::frag(As, wr * 32 * WT + mt * 32 + li, hh, a[mt]);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) fetch_frag<BT>(Bs, wc * 64 + nt * 32 + li, hh, b[nt]);
+        for (int nt = 0; nt < WT; ++nt) TileMover<BT, T>::frag(Bs, wc * 32 * WT + nt * 32 + li, hh, b[nt]);
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < WT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < WT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
         __syncthreads();
     }
 
     // C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < WT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wc * 64 + nt * 32 + li;
+        for (int nt = 0; nt < WT; ++nt) {
+            const int n = n0 + wc * 32 * WT + nt * 32 + li;
             if (n >= g.N) continue;
             const float bias = g.bias ? g.bias[n] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int64_t row = m0 + wr * 32 * WT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[mt][nt][r] + bias;
                 if (g.emb) {
                     const int tr = (row < g.rows_valid) ? (int)g.tvec[row] : 0;
@@ -137,7 +167,12 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
 template <bool AT, bool BT>
 int launch(const G2& g, hipStream_t s) {
     const int splits = (g.K + g.kchunk - 1) / g.kchunk;
-    hipLaunchKernelGGL((k_gemm2<AT, BT>), dim3((unsigned)(g.M / TM), (unsigned)((g.N + TN - 1) / TN), (unsigned)splits), dim3(256), 0, s, g);
+    const int64_t wg128 = (int64_t)(g.M / TM) * ((g.N + TN - 1) / TN) * splits;
+    if (wg128 >= 512) {
+        hipLaunchKernelGGL((k_gemm2<AT, BT, 2>), dim3((unsigned)(g.M / 128), (unsigned)((g.N + 127) / 128), (unsigned)splits), dim3(256), 0, s, g);
+    } else {
+        hipLaunchKernelGGL((k_gemm2<AT, BT, 1>), dim3((unsigned)(g.M / 64), (unsigned)((g.N + 63) / 64), (unsigned)splits), dim3(256), 0, s, g);
+    }
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
@@ -473,7 +508,7 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.A = dy; g.lda = l.out_pad; g.B = tr.act[i]; g.ldb = l.in_pad;
         g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
         if ((rc = launch<true, true>(g, s))) return rc;
-        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 64), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
+        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 256), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
         G2 d{};
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
@@ -491,7 +526,7 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
         g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
         if ((rc = launch<true, false>(g, s))) return rc;
-        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 64), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
+        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 256), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
         hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(256), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld);
     }
     {   // time-embedding MLP over the T-row table
