@@ -77,8 +77,6 @@ def main():
     eng.set_math("fast")
     # denoiser alone, shape M
     for prec in ("bf16", "fp32"):
-        if prec == "bf16" and a.hidden != 512:
-            continue
         secs = timeit(lambda: eng.mlp_forward(x_in, t, out=out, precision=prec, x_strides=(1, B), out_strides=(1, B), B=B), iters=5)
         fl = 2 * (D * 128 + 128 * a.hidden + 3 * a.hidden ** 2 + a.hidden * D)
         peak = 2500.0 if prec == "bf16" else 157.3
@@ -86,8 +84,6 @@ def main():
                           "frac_of_peak": B * fl / secs / 1e12 / peak, "rows_per_s": B / secs}), flush=True)
     # whole mixed_loss (Philox) and reverse row-steps per second
     for prec in ("bf16", "fp32"):
-        if prec == "bf16" and a.hidden != 512:
-            continue
         d.precision = prec
         secs = timeit(lambda: d.mixed_loss_rows(x0, timestep=t, seed=7), iters=5)
         print(json.dumps({"path": f"mixed_loss_rows {prec} (q_sample + denoiser + loss_rows)", "rows": B, "ms": secs * 1e3, "evals_per_s": B / secs}), flush=True)

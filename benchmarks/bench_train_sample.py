@@ -43,7 +43,7 @@ def main():
 
     fl_fwd = 2 * (D * 128 + 128 * a.hidden + 3 * a.hidden * a.hidden + a.hidden * D)
     # ---- reverse sampling: rows / s at T steps (config 4)
-    for prec in (["bf16"] if a.hidden == 512 else []) + ["fp32"]:
+    for prec in ("bf16", "fp32"):
         d = make(prec)
         rows = a.rows if prec == "bf16" else max(a.rows // 8, 1024)
         d.sample(1024, torch.ones(1))  # warm-up

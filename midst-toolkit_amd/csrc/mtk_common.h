@@ -95,6 +95,11 @@ struct mtk_ctx {
     float* d_bias_all = nullptr;  // concatenated padded biases for the fused kernel
     float* d_embb = nullptr;      // [T][emb_ld] time-embedding table + proj bias (fused kernel)
     bool fused_ok = false;
+    // layered bf16 path (mtk_mlp_bf16_layered.hip): bf16 weight images per layer + activation ping-pong
+    std::vector<void*> wb16;
+    std::vector<float*> bb16;
+    void* ws16[2] = {nullptr, nullptr};
+    size_t ws16_elems = 0;
     int fused_h = 0;
     // workspace for the layered fp32 path
     float* ws[2] = {nullptr, nullptr};

@@ -11,6 +11,10 @@
 int mtk_pack_fused(mtk_ctx* c, hipStream_t s);    // mtk_mlp_bf16.hip
 void mtk_free_fused(mtk_ctx* c);                  // mtk_mlp_bf16.hip
 void mtk_free_train(mtk_ctx* c);                  // mtk_train.hip
+void mtk_free_layered(mtk_ctx* c);                // mtk_mlp_bf16_layered.hip
+int mtk_pack_layered(mtk_ctx* c, hipStream_t s);  // mtk_mlp_bf16_layered.hip
+int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                             float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16_layered.hip
 int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                       float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16.hip
 
@@ -198,6 +202,7 @@ void mtk_free_mlp(mtk_ctx* c) {
     }
     c->tf_ws_elems = 0;
     mtk_free_fused(c);
+    mtk_free_layered(c);
     mtk_free_train(c);
     c->have_weights = false;
 }
@@ -257,7 +262,9 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
     (void)hipFree(e0);
     (void)hipFree(e1);
     c->have_weights = true;
-    return mtk_pack_fused(c, s);
+    if ((rc = mtk_pack_fused(c, s))) return rc;
+    // shapes the fused kernel does not cover get bf16 weight images for the layer-by-layer bf16 MFMA path
+    return c->fused_ok ? MTK_OK : mtk_pack_layered(c, s);
 }
 
 // Exact-fp32 forward for `B` rows starting at x / out.
@@ -316,8 +323,9 @@ extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_
     MTK_HIP(hipSetDevice(c->device));
     if (precision == MTK_PREC_FP32) return forward_f32(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
     if (precision == MTK_PREC_BF16) {
-        if (!c->fused_ok) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward: the fused bf16 kernel does not support this denoiser shape");
-        return mtk_fused_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
+        if (c->fused_ok) return mtk_fused_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
+        if (c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward: the bf16 images do not track a training state; detach it (set the weights again) first");
+        return mtk_layered_bf16_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
     }
     MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward: unknown precision %d", precision);
 }

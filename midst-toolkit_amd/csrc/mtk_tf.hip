@@ -59,11 +59,12 @@ extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_
     MTK_HIP(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     if (precision == MTK_PREC_BF16) {
-        if (!c->fused_ok) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: the fused bf16 kernel does not support this denoiser shape");
-        const int rc = mtk_fused_tf_score(c, B, P, x, x_ld, noise, n_t, t_list_host, add_t, score, s);
-        // wide records / large noise tables do not fit the fused kernel's LDS staging: same arithmetic as three kernels
-        // (noising, bf16 MFMA denoiser, MSE) below
-        if (rc != MTK_ERR_UNSUPPORTED) return rc;
+        // denoiser shapes, wide records or large noise tables the fused kernel does not cover: same arithmetic as three
+        // kernels (noising, bf16 MFMA denoiser — fused or layer-by-layer —, MSE) below
+        if (c->fused_ok) {
+            const int rc = mtk_fused_tf_score(c, B, P, x, x_ld, noise, n_t, t_list_host, add_t, score, s);
+            if (rc != MTK_ERR_UNSUPPORTED) return rc;
+        }
     } else if (precision != MTK_PREC_FP32) {
         MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: unknown precision %d", precision);
     }

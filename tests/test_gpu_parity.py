@@ -328,6 +328,36 @@ def test_mlp_forward_bf16(tag):
         assert torch.equal(o, out[:n]), n
 
 
+@pytest.mark.parametrize("shape", [(120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512]), (40, [128, 256])])
+def test_mlp_forward_bf16_layered(shape):
+    """Denoiser shapes outside the fused kernel (hidden width != 512, unequal widths, D > 128) run layer by layer
+    on bf16 MFMA: same bars as the fused kernel."""
+    import midst_toolkit_amd as mtk
+
+    D, layers = shape
+    params = orc.init_mlp_params(D, layers, seed=3)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(layers), 0.0)).to(dev())
+    net.load_state_dict(params, strict=True)
+    net.precision = "bf16"
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((300, D), generator=g)
+    t = torch.randint(0, 1000, (300,), generator=g)
+    with torch.no_grad():
+        out = net(x.to(dev()), t.to(dev()))
+    want = orc.mlp_forward(params, x, t)
+    scale = float(want.abs().max())
+    assert float((out.cpu() - want).abs().max()) <= BF16_TOL * scale
+    ref = bf16_emulated_forward(params, x, t)
+    assert float((out.cpu() - ref).abs().max()) <= 2e-3 * scale, float((out.cpu() - ref).abs().max()) / scale
+    eng = net.engine(dev())
+    for n in (1, 127, 129):
+        o = eng.mlp_forward(x[:n].to(dev()).contiguous(), t[:n].to(dev()).contiguous(), precision="bf16")
+        assert torch.equal(o, out[:n]), n
+    o2 = torch.empty((D, 300), device=dev())  # column-major in and out
+    eng.mlp_forward(x.t().contiguous().to(dev()), t.to(dev()), out=o2, precision="bf16", x_strides=(1, 300), out_strides=(1, 300), B=300)
+    assert torch.equal(o2.t().contiguous(), out)
+
+
 def bf16_emulated_forward(params, x, t):
     """fp32 math on bf16-rounded weights and activations (what the fused kernel computes, up to
     summation order)."""
