@@ -20,6 +20,7 @@ struct Staged {
     const SchedRow* rows;
     const int32_t* off;
     const float* logK;
+    unsigned char* end;  // first free byte of dynamic LDS after the tables (16-byte aligned)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mtk_smem[];
@@ -44,6 +45,7 @@ __device__ __forceinline__ Staged stage_tables(const DevTables& d) {
     for (int i = threadIdx.x; i < d.C; i += blockDim.x) sk[i] = d.logK[i];
     s.off = so;
     s.logK = sk;
+    s.end = mtk_smem + ((((reinterpret_cast<unsigned char*>(sk + (d.C > 0 ? d.C : 1)) - mtk_smem) + 15) >> 4) << 4);
     __syncthreads();
     return s;
 }
@@ -486,6 +488,33 @@ struct PhiloxW {
 constexpr int kGroup = 8;
 constexpr int kKCache = 16;
 
+// The reference's record matrix is row-major: a lane reading "its" row makes every load touch 64 different cache
+// lines (120-byte stride), and 30 such loads per record wave cost more L1 tag cycles than the whole kernel's
+// coalesced traffic.  When the rows are at most kStageLd floats wide a wave copies its 64 rows (one contiguous span)
+// into a private LDS slab with 16-byte coalesced loads and each lane then reads its row from LDS (lgkmcnt, not vmcnt:
+// nothing later in the row waits behind the kernel's stores).
+constexpr int kStageLd = 32;
+__device__ __forceinline__ const float* stage_rows(float* slab, const float* x0, int64_t ld, int64_t row_base, int64_t B, int lane) {
+    const int64_t left = B - row_base;
+    const int nrow = left < 64 ? (int)left : 64;
+    const float* src = x0 + row_base * ld;
+    const int nflt = nrow * (int)ld;
+    if (nrow == 64) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(slab);
+        for (int i = lane; i < nflt / 4; i += 64) d4[i] = s4[i];
+    } else {
+        for (int i = lane; i < nflt; i += 64) slab[i] = src[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return slab + lane * ld;
+}
+__device__ __forceinline__ void stage_done() {  // before the slab is overwritten by the next record wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // raw logits of one categorical block, held in registers when the block has at most kKCache columns
 struct BlockRaw {
     float v[kKCache];
@@ -532,13 +561,23 @@ struct BlockExp {
 struct CachedTag { static constexpr bool value = true; };
 struct StreamTag { static constexpr bool value = false; };
 
-template <bool LDS_ROWS>
+template <bool LDS_ROWS, bool STAGE>
 __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
-    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+    const int lane = threadIdx.x & 63;
+    float* slab = reinterpret_cast<float*>(s.end) + (threadIdx.x >> 6) * 64 * (STAGE ? (int)a.x0_ld : 0);
+    // the loop bound is wave-uniform (first row of the wave): all 64 lanes take part in the staging
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row - lane < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const float* xr;
+        if (STAGE) {
+            stage_done();
+            xr = stage_rows(slab, a.x0, a.x0_ld, row - lane, a.B, lane);
+        } else {
+            xr = a.x0 + row * a.x0_ld;
+        }
+        if (row >= a.B) continue;
         const int t = (int)a.t[row];
-        const float* xr = a.x0 + row * a.x0_ld;
         float* xo = a.x_in + row * a.xi_rs;
         // first group of inputs in flight before anything is consumed
         float xv[kGroup], ev[kGroup];
@@ -621,15 +660,24 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
 
 struct TruePost { float lt_c0, lt_ct, w_c0, w_ct, w_cc, w_sum, self; };
 
-template <bool LDS_ROWS>
+template <bool LDS_ROWS, bool STAGE>
 __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
     const SchedRow srT = s.rows[T - 1];
-    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+    const int lane = threadIdx.x & 63;
+    float* slab = reinterpret_cast<float*>(s.end) + (threadIdx.x >> 6) * 64 * (STAGE ? (int)a.x0_ld : 0);
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row - lane < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const float* xr;
+        if (STAGE) {  // x_0's category codes come from the wave's LDS slab (stage_rows above)
+            stage_done();
+            xr = stage_rows(slab, a.x0, a.x0_ld, row - lane, a.B, lane);
+        } else {
+            xr = a.x0 ? a.x0 + row * a.x0_ld : nullptr;
+        }
+        if (row >= a.B) continue;
         const int t = (int)a.t[row];
         const float* mo = a.mo + row * a.mo_rs;
-        const float* xr = a.x0 ? a.x0 + row * a.x0_ld : nullptr;
         const bool multi = a.loss_multi && C > 0;
         // the first categorical block's inputs go out before the Gaussian part is consumed
         BlockRaw raw;
@@ -1048,7 +1096,16 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
     MTK_HIP(hipSetDevice(ctx->device));
     QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0};
     const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
-    auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true> : k_q_sample_fast<false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
+    // fast math: stage the row-major records through LDS when they are narrow and 16-byte aligned (the slab
+    // replaces the LDS copy of the schedule rows, which then come from L2: measured equal)
+    const bool stage = ctx->fast_math && x0_ld <= kStageLd && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && !getenv("MTK_NO_STAGE");
+    if (stage) {
+        hipLaunchKernelGGL((k_q_sample_fast<false, true>), dim3(grid_for(B)), dim3(kBlock),
+                           lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
+    }
+    auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true, false> : k_q_sample_fast<false, false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -1065,7 +1122,14 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     MTK_HIP(hipSetDevice(ctx->device));
     LossArgs a{ctx->dev(), B, model_out, mo_rs, mo_cs, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, seed, row0};
     const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
-    auto k = ctx->fast_math ? (lds ? k_loss_rows_fast<true> : k_loss_rows_fast<false>) : (lds ? k_loss_rows<true> : k_loss_rows<false>);
+    const bool stage = ctx->fast_math && loss_multi && ctx->C > 0 && x0_ld <= kStageLd && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && !getenv("MTK_NO_STAGE");
+    if (stage) {  // as in mtk_q_sample
+        hipLaunchKernelGGL((k_loss_rows_fast<false, true>), dim3(grid_for(B)), dim3(kBlock),
+                           lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
+    }
+    auto k = ctx->fast_math ? (lds ? k_loss_rows_fast<true, false> : k_loss_rows_fast<false, false>) : (lds ? k_loss_rows<true> : k_loss_rows<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;

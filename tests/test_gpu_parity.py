@@ -469,6 +469,38 @@ def test_fast_math_against_oracle(tag, monkeypatch):
         check_categorical(zid.t(), want_zi, logp, uu, c["K"])
 
 
+def test_fast_math_staged_rows_equal_direct_rows():
+    """The fast kernels copy a wave's 64 row-major records into LDS when x0 is 16-byte aligned and narrow, and read
+    them through strides otherwise: same arithmetic, so outputs are identical — full waves and a ragged last wave."""
+    c = load_case("M_mixed")
+    B, Nn, C, D = 64 * 15 + 40, c["Nn"], c["C"], c["D"]
+    d = build(c)
+    d.math = "fast"
+    eng = d.engine()
+    x0, t, eps, u = _big_mixed_batch(c, B, seed=5)
+    ld = x0.shape[1]
+    aligned = x0.to(dev())
+    buf = torch.empty(B * ld + 1, device=dev())
+    direct = buf[1:].view(B, ld)
+    direct.copy_(aligned)
+    assert aligned.data_ptr() % 16 == 0 and direct.data_ptr() % 16 != 0
+    g = torch.Generator().manual_seed(9)
+    out = colmajor(torch.randn((B, D), generator=g) * 2)
+    res = []
+    for x in (aligned, direct):
+        x_in = torch.empty((D, B), device=dev())
+        idx = torch.empty((C, B), dtype=torch.int32, device=dev())
+        eng.q_sample(x, t.to(dev()), eps.to(dev()), u.to(dev()), x_in, (1, B), idx)
+        x_in2 = torch.empty((D, B), device=dev())
+        idx2 = torch.empty((C, B), dtype=torch.int32, device=dev())
+        eng.q_sample(x, t.to(dev()), None, None, x_in2, (1, B), idx2, seed=31)
+        lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+        eng.loss_rows(out, (1, B), x, idx, eps.to(dev()), t.to(dev()), lm, lg)
+        res.append((x_in, idx, x_in2, idx2, lm, lg))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_fast_math_philox_statistics():
     """In-kernel noise + fast math: the loss of a fixed batch agrees with the injected-noise reference
     value in distribution (different random stream, so only the mean over many records is compared)."""
