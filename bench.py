@@ -53,6 +53,20 @@ def cpu_baseline(params, Nn, T, seed, seconds_target=10.0):
             "sample": f"{n_rec} records x {n_t} timesteps x 1 noise draw, oracle/diffusion_oracle.tf_score (PyTorch-CPU eager), {dt:.1f} s"}
 
 
+class _HostGather:
+    """Rehearsal only (MTK_BENCH_BACKEND=gloo): an asynchronous all-gather through host tensors with the
+    .wait() of a torch.distributed work handle."""
+
+    def __init__(self, dist, src, dst, world):
+        self.host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+        self.dst = dst
+        self.work = dist.all_gather(self.host, src.cpu(), async_op=True)
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(torch.stack(self.host))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,18 +79,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr
+        import faulthandler
+
+        faulthandler.dump_traceback_later(60, exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    # MTK_BENCH_BACKEND=gloo rehearses the N > 1 control flow with several ranks on one card (RCCL refuses that)
+    backend = os.environ.get("MTK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import midst_toolkit_amd as mtk
     from midst_toolkit_amd import scoring
@@ -94,16 +119,36 @@ def main():
     x = torch.randn((a.records, Nn), generator=g).clamp(-5.2, 5.2).to(dev)  # this rank's shard, resident
     noise = torch.randn((P, Nn), generator=torch.Generator().manual_seed(seed)).to(dev)  # shared table
     eng = diff.engine()
-    scores = torch.empty((a.nt, a.records, P), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, a.nt, a.records, P), dtype=torch.float32, device=dev) if world > 1 else None
+    # N > 1: the only exchange of the path is the gather of the score blocks.  It runs on RCCL's own stream while the
+    # next step's kernel computes into the other buffer pair (double buffered); a step waits, stream-side, only for
+    # the gather that last used its pair.  Every gather is drained inside the timed region.
+    nbuf = 2 if world > 1 else 1
+    scores = [torch.empty((a.nt, a.records, P), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    gathered = [torch.empty((world, a.nt, a.records, P), dtype=torch.float32, device=dev) for _ in range(nbuf)] if world > 1 else None
+    pending = [None] * nbuf
 
-    def step(i):
+    def step(i, events=None):
+        b = i % nbuf
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
         ts = [(i * a.nt + k) % T for k in range(a.nt)]
-        eng.tf_score(x, noise, ts, 0, a.precision, out=scores)
+        if events:
+            events[0].record()
+        eng.tf_score(x, noise, ts, 0, a.precision, out=scores[b])
+        if events:
+            events[1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, scores)
+            if backend == "nccl":
+                pending[b] = dist.all_gather_into_tensor(gathered[b], scores[b], async_op=True)
+            else:  # gloo rehearsal of the control flow: staged through host tensors
+                pending[b] = _HostGather(dist, scores[b], gathered[b], world)
 
     def barrier():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -115,13 +160,16 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for i in range(a.steps):
-        ev[i][0].record()
-        eng.tf_score(x, noise, [((a.warmup + i) * a.nt + k) % T for k in range(a.nt)], 0, a.precision, out=scores)
-        ev[i][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, scores)
+        step(a.warmup + i, ev[i])
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived in rank order
+        last = (a.warmup + a.steps - 1) % nbuf
+        assert torch.equal(gathered[last][rank], scores[last])
+        mine = torch.stack([t.flatten()[:4] for t in gathered[last]])
+        ref = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(ref, mine)
+        assert all(torch.equal(r, mine) for r in ref)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

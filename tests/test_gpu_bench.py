@@ -1,0 +1,42 @@
+"""bench.py's contract on the GPU: the one JSON line at N = 1, and a two-rank rehearsal of the N > 1 control flow
+(double-buffered score blocks, asynchronous gather drained inside the timed region).  Two ranks cannot share one
+card under RCCL, so the rehearsal runs the same loop with the gather staged through gloo (MTK_BENCH_BACKEND=gloo);
+MTK_BENCH_CHECK makes every rank verify that its own block and every peer's arrived in rank order."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_single_gpu():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--records", "8192", "--nt", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _last_json(r.stdout)
+    assert KEYS <= set(out) and out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert "workload" in out["config"]
+
+
+def test_bench_two_rank_rehearsal():
+    env = dict(os.environ, MTK_BENCH_BACKEND="gloo", MTK_BENCH_CHECK="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
