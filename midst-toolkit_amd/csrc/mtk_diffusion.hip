@@ -958,102 +958,114 @@ template <bool FAST> __device__ __forceinline__ float lae_t(float a, float b) {
     return m + lg<FAST>(ex<FAST>(a - m) + ex<FAST>(b - m));
 }
 
-template <bool LDS_ROWS, bool FAST>
-__global__ __launch_bounds__(kBlock) void k_loss_grad(LossGradArgs a) {
-    const Staged s = stage_tables<LDS_ROWS>(a.d);
+// One workgroup = 64 records x kLgWaves waves.  A lane-per-record loop over the C blocks is a chain of ~6 dependent
+// memory passes per block (110 us at any batch size the trainer uses); here wave w takes the categorical blocks
+// k = w, w + kLgWaves, ... and the numeric columns j = w, w + kLgWaves, ... of the same 64 records, and the per-record
+// partial losses meet in LDS, summed in wave order (deterministic).
+constexpr int kLgWaves = 8;
+
+template <bool FAST>
+__global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
+    const Staged s = stage_tables<false>(a.d);
+    __shared__ float part_g[kLgWaves][64], part_m[kLgWaves][64];
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
     const SchedRow srT = s.rows[T - 1];
-    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
-        const int t = (int)a.t[row];
-        const float* mo = a.out + row;
-        float* go = a.dout + row;
-        if (Nn > 0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < a.B; base += (int64_t)gridDim.x * 64) {
+        const int64_t row = base + lane;
+        float accg = 0.0f, accm = 0.0f;
+        if (row < a.B) {
+            const int t = (int)a.t[row];
+            const float* mo = a.out + row;
+            float* go = a.dout + row;
             PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
             PhiloxNF pf(a.seed, a.row0 + row, MTK_STREAM_EPS);
-            float acc = 0.0f;
-            for (int j = 0; j < Nn; ++j) {
+            for (int j = w; j < Nn; j += kLgWaves) {
                 const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
                 const float df = mo[j * a.ld] - e;
-                acc += df * df;
+                accg += df * df;
                 go[j * a.ld] = a.gscale * df;
             }
-            if (a.loss_gauss) a.loss_gauss[row] = acc / (float)Nn;
-        }
-        if (C == 0) continue;
-        const SchedRow st = s.rows[t];
-        const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
-        const float* xr = a.x0 + row * a.x0_ld;
-        float kl = 0.0f, nll = 0.0f, prior = 0.0f;
-        for (int k = 0; k < C; ++k) {
-            const int o = s.off[k], Kk = s.off[k + 1] - o;
-            const float logK = s.logK[k];
-            const int c0 = (int)(long long)xr[Nn + k];
-            const int ct = a.xt_idx[(int64_t)k * a.B + row];
-            const float* mc = mo + (int64_t)(Nn + o) * a.ld;
-            float* gc = go + (int64_t)(Nn + o) * a.ld;
-            const float cq = st.log_1m_alpha - logK;
-            const float q_hot = lae_t<FAST>(0.0f + st.log_alpha, cq), q_cold = lae_t<FAST>(MTK_LOG_TINY + st.log_alpha, cq);
-            const float ce = s1.log_1m_acp - logK;
-            const float e_hot = (t == 0) ? 0.0f : lae_t<FAST>(0.0f + s1.log_acp, ce);
-            const float e_cold = (t == 0) ? MTK_LOG_TINY : lae_t<FAST>(MTK_LOG_TINY + s1.log_acp, ce);
-            const float v_c0 = e_hot + ((c0 == ct) ? q_hot : q_cold);
-            const float v_ct = e_cold + q_hot;
-            const float v_cc = e_cold + q_cold;
-            const int n_cc = Kk - ((c0 == ct) ? 1 : 2);
-            const float m_t = fmaxf(v_c0, fmaxf(v_ct, v_cc));
-            float b_t = ex<FAST>(v_c0 - m_t) + (float)n_cc * ex<FAST>(v_cc - m_t);
-            if (c0 != ct) b_t += ex<FAST>(v_ct - m_t);
-            const float lse_t = m_t + lg<FAST>(b_t);
-            const float lt_c0 = v_c0 - lse_t, lt_ct = v_ct - lse_t, lt_cc = v_cc - lse_t;
-            const float w_c0 = ex<FAST>(lt_c0), w_ct = ex<FAST>(lt_ct), w_cc = ex<FAST>(lt_cc);
-            const float w_sum = w_c0 + (float)n_cc * w_cc + ((c0 != ct) ? w_ct : 0.0f);
-            float mx = -INFINITY;
-            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.ld]);
-            float sum = 0.0f;
-            for (int i = 0; i < Kk; ++i) sum += ex<FAST>(mc[i * a.ld] - mx);
-            const float lsum = lg<FAST>(sum);
-            const float ev_top = (t == 0) ? -lsum : lae_t<FAST>(-lsum + s1.log_acp, ce);
-            const float m_m = ev_top + q_hot;
-            float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
-            for (int i = 0; i < Kk; ++i) {
-                const float lsm = (mc[i * a.ld] - mx) - lsum;
-                const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
-                const float un = ev + ((i == ct) ? q_hot : q_cold);
-                b_m += ex<FAST>(un - m_m);
-                const float lt = (i == c0) ? lt_c0 : ((i == ct) ? lt_ct : lt_cc);
-                const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
-                acc_kl += w * (lt - un);
-                if (i == c0) un_c0 = un;
-            }
-            const float lse_m = m_m + lg<FAST>(b_m);
-            kl += acc_kl + lse_m * w_sum;
-            nll += un_c0 - lse_m;
-            const float cT = srT.log_1m_acp - logK;
-            const float p_hot = lae_t<FAST>(0.0f + srT.log_acp, cT), p_cold = lae_t<FAST>(MTK_LOG_TINY + srT.log_acp, cT);
-            prior += ex<FAST>(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (ex<FAST>(p_cold) * (p_cold + logK));
-            // gradient: first pass stores g_i and accumulates their sum, second pass projects through the softmax
-            float G = 0.0f;
-            for (int i = 0; i < Kk; ++i) {
-                const float lsm = (mc[i * a.ld] - mx) - lsum;
-                const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
-                const float un = ev + ((i == ct) ? q_hot : q_cold);
-                const float p = ex<FAST>(un - lse_m);
-                const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
-                const float gun = (t == 0) ? (p - ((i == c0) ? 1.0f : 0.0f)) : (p * w_sum - w);
-                const float sl = (t == 0) ? 1.0f : ex<FAST>((lsm + s1.log_acp) - ev);
-                const float gi = gun * sl;
-                G += gi;
-                gc[i * a.ld] = gi;
-            }
-            for (int i = 0; i < Kk; ++i) {
-                const float sm = ex<FAST>((mc[i * a.ld] - mx) - lsum);
-                gc[i * a.ld] = a.mscale * (gc[i * a.ld] - sm * G);
+            const SchedRow st = s.rows[t];
+            const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
+            const float* xr = a.x0 + row * a.x0_ld;
+            for (int k = w; k < C; k += kLgWaves) {
+                const int o = s.off[k], Kk = s.off[k + 1] - o;
+                const float logK = s.logK[k];
+                const int c0 = (int)(long long)xr[Nn + k];
+                const int ct = a.xt_idx[(int64_t)k * a.B + row];
+                const float* mc = mo + (int64_t)(Nn + o) * a.ld;
+                float* gc = go + (int64_t)(Nn + o) * a.ld;
+                const float cq = st.log_1m_alpha - logK;
+                const float q_hot = lae_t<FAST>(0.0f + st.log_alpha, cq), q_cold = lae_t<FAST>(MTK_LOG_TINY + st.log_alpha, cq);
+                const float ce = s1.log_1m_acp - logK;
+                const float e_hot = (t == 0) ? 0.0f : lae_t<FAST>(0.0f + s1.log_acp, ce);
+                const float e_cold = (t == 0) ? MTK_LOG_TINY : lae_t<FAST>(MTK_LOG_TINY + s1.log_acp, ce);
+                const float v_c0 = e_hot + ((c0 == ct) ? q_hot : q_cold);
+                const float v_ct = e_cold + q_hot;
+                const float v_cc = e_cold + q_cold;
+                const int n_cc = Kk - ((c0 == ct) ? 1 : 2);
+                const float m_t = fmaxf(v_c0, fmaxf(v_ct, v_cc));
+                float b_t = ex<FAST>(v_c0 - m_t) + (float)n_cc * ex<FAST>(v_cc - m_t);
+                if (c0 != ct) b_t += ex<FAST>(v_ct - m_t);
+                const float lse_t = m_t + lg<FAST>(b_t);
+                const float lt_c0 = v_c0 - lse_t, lt_ct = v_ct - lse_t, lt_cc = v_cc - lse_t;
+                const float w_c0 = ex<FAST>(lt_c0), w_ct = ex<FAST>(lt_ct), w_cc = ex<FAST>(lt_cc);
+                const float w_sum = w_c0 + (float)n_cc * w_cc + ((c0 != ct) ? w_ct : 0.0f);
+                float mx = -INFINITY;
+                for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.ld]);
+                float sum = 0.0f;
+                for (int i = 0; i < Kk; ++i) sum += ex<FAST>(mc[i * a.ld] - mx);
+                const float lsum = lg<FAST>(sum);
+                const float ev_top = (t == 0) ? -lsum : lae_t<FAST>(-lsum + s1.log_acp, ce);
+                const float m_m = ev_top + q_hot;
+                float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
+                for (int i = 0; i < Kk; ++i) {
+                    const float lsm = (mc[i * a.ld] - mx) - lsum;
+                    const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
+                    const float un = ev + ((i == ct) ? q_hot : q_cold);
+                    b_m += ex<FAST>(un - m_m);
+                    const float lt = (i == c0) ? lt_c0 : ((i == ct) ? lt_ct : lt_cc);
+                    const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
+                    acc_kl += w * (lt - un);
+                    if (i == c0) un_c0 = un;
+                }
+                const float lse_m = m_m + lg<FAST>(b_m);
+                const float cT = srT.log_1m_acp - logK;
+                const float p_hot = lae_t<FAST>(0.0f + srT.log_acp, cT), p_cold = lae_t<FAST>(MTK_LOG_TINY + srT.log_acp, cT);
+                const float prior_k = ex<FAST>(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (ex<FAST>(p_cold) * (p_cold + logK));
+                accm += ((t == 0) ? -(un_c0 - lse_m) : (acc_kl + lse_m * w_sum)) * (float)T + prior_k;
+                // gradient: first pass stores g_i and accumulates their sum, second pass projects through the softmax
+                float G = 0.0f;
+                for (int i = 0; i < Kk; ++i) {
+                    const float lsm = (mc[i * a.ld] - mx) - lsum;
+                    const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
+                    const float un = ev + ((i == ct) ? q_hot : q_cold);
+                    const float p = ex<FAST>(un - lse_m);
+                    const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
+                    const float gun = (t == 0) ? (p - ((i == c0) ? 1.0f : 0.0f)) : (p * w_sum - w);
+                    const float sl = (t == 0) ? 1.0f : ex<FAST>((lsm + s1.log_acp) - ev);
+                    const float gi = gun * sl;
+                    G += gi;
+                    gc[i * a.ld] = gi;
+                }
+                for (int i = 0; i < Kk; ++i) {
+                    const float sm = ex<FAST>((mc[i * a.ld] - mx) - lsum);
+                    gc[i * a.ld] = a.mscale * (gc[i * a.ld] - sm * G);
+                }
             }
         }
-        if (a.loss_multi) {
-            const float lt = (t == 0) ? -nll : kl;
-            a.loss_multi[row] = (lt * (float)T + prior) / (float)C;
+        part_g[w][lane] = accg;
+        part_m[w][lane] = accm;
+        __syncthreads();
+        if (w == 0 && row < a.B) {
+            float g = 0.0f, m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kLgWaves; ++i) { g += part_g[i][lane]; m += part_m[i][lane]; }
+            if (a.loss_gauss && Nn > 0) a.loss_gauss[row] = g / (float)Nn;
+            if (a.loss_multi && C > 0) a.loss_multi[row] = m / (float)C;
         }
+        __syncthreads();
     }
 }
 
@@ -1078,9 +1090,9 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
     LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
                    ctx->Nn > 0 ? (float)(2.0 * inv_global_batch / ctx->Nn) : 0.0f,
                    ctx->C > 0 ? (float)((double)ctx->T * inv_global_batch / ctx->C) : 0.0f, seed, row0};
-    const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
-    auto k = ctx->fast_math ? (lds ? k_loss_grad<true, true> : k_loss_grad<false, true>) : (lds ? k_loss_grad<true, false> : k_loss_grad<false, false>);
-    hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), stream, a);
+    int64_t grid = (B + 63) / 64;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(ctx->fast_math ? k_loss_grad<true> : k_loss_grad<false>, dim3((unsigned)grid), dim3(64 * kLgWaves), lds_bytes(ctx, false), stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
