@@ -43,8 +43,9 @@ enum mtk_status {
 };
 
 /* Row order of tables_host passed to mtk_ctx_create: MTK_NTAB rows of T doubles each.  Rows 0..9
- * hold the reference's fp32 buffers (exactly representable in a double); row 10 is the fp64
- * log-variance row of the reverse chain, which the reference never casts to fp32 (GMD:223, 387-394). */
+ * hold the reference's fp32 buffers (exactly representable in a double); rows 10 and 11 are the fp64
+ * log-variance and variance rows of the reverse chain, which the reference never casts to fp32
+ * (GMD:223, 387-394). */
 enum mtk_table {
     MTK_TAB_SQRT_ACP = 0,       /* sqrt_alphas_cumprod            GMD:263 */
     MTK_TAB_SQRT_1M_ACP = 1,    /* sqrt_one_minus_alphas_cumprod  GMD:264 */
@@ -57,7 +58,8 @@ enum mtk_table {
     MTK_TAB_POST_COEF1 = 8,     /* posterior_mean_coef1           GMD:226 */
     MTK_TAB_POST_COEF2 = 9,     /* posterior_mean_coef2           GMD:228-230 */
     MTK_TAB_MODEL_LOGVAR64 = 10, /* log([posterior_variance[1], (1-alphas)[1:]]) in fp64, GMD:387-394 */
-    MTK_NTAB = 11
+    MTK_TAB_MODEL_VAR64 = 11,   /* [posterior_variance[1], (1-alphas)[1:]] in fp64 (the "variance" of GMD:425, used by condition_mean GMD:615) */
+    MTK_NTAB = 12
 };
 
 /* Denoiser arithmetic. */
@@ -150,6 +152,17 @@ int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step, const floa
                       int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64, const float* u,
                       float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0,
                       mtk_stream stream);
+
+/* The same step with classifier guidance: replaces gaussian_p_sample's conditioning_function branch (GMD:699-702)
+ * = condition_mean (GMD:585-615): mean <- float(mean) + variance * grad, where grad [B, Nn] row-major fp32 is what the
+ * caller's conditioning_function(features, timestep) returned for the CURRENT state z (the callback itself - a torch
+ * classifier and its autograd - stays on the caller's side) and variance is the fp64 model variance of t.  grad may be
+ * NULL (then identical to mtk_p_sample_step).  Used by sample(..., conditioning_function) and conditional_sample
+ * (GMD:1319). */
+int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
+                             int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64, const float* u,
+                             const float* grad, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0,
+                             mtk_stream stream);
 
 /* Replaces the initial draw of sample() (GMD:1392-1399): z0 [B, Nn] row-major fp32 (or NULL → Philox)
  * into the fp64 state z [Nn][B]; categories by Gumbel-argmax of uniform logits from u0 [B, S]

@@ -278,6 +278,8 @@ struct StepArgs {
     // fp32 coefficients of this t and the fp64 standard deviation exp(0.5 * model_log_variance[t])
     float sqrt_recip, sqrt_recipm1, coef1, coef2, log_alpha, log_1m_alpha, log_acp_prev, log_1m_acp_prev;
     double sigma;
+    double variance;    // model variance of this t (fp64), used with grad
+    const float* grad;  // optional [B, Nn] row-major: classifier guidance, mean <- float(mean) + variance * grad (GMD:614-615)
     const float* mo; int64_t mo_rs, mo_cs;
     double* z;
     int32_t* z_idx;
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
                 const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
                 mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
             }
+            if (a.grad) mean = (double)(float)mean + a.variance * (double)a.grad[row * Nn + j];
             const double mask = (t != 0) ? 1.0 : 0.0;
             const double zn = mean + (mask * a.sigma) * nz;
             *zp = zn;
@@ -849,6 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                         const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh[i]);
                         mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
                     }
+                    if (a.grad) mean = (double)(float)mean + a.variance * (double)a.grad[row * Nn + j];
                     const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
                     a.z[(int64_t)j * a.B + row] = zn;
                     if (xo) xo[j * a.xi_cs] = (float)zn;
@@ -1147,10 +1151,10 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     return MTK_OK;
 }
 
-extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
-                                 int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64,
-                                 const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed,
-                                 uint64_t row0, mtk_stream stream) {
+extern "C" int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
+                                        int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64,
+                                        const float* u, const float* grad, float* x_in_next, int64_t xi_rs, int64_t xi_cs,
+                                        uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: null context");
     if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: t = %d outside [0, %d)", t, ctx->T);
     if (B < 0 || !model_out || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: null pointer or negative B");
@@ -1169,6 +1173,8 @@ extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step,
     a.log_acp_prev = (float)ctx->tab(MTK_TAB_LOG_ACP, tp);
     a.log_1m_acp_prev = (float)ctx->tab(MTK_TAB_LOG_1M_ACP, tp);
     a.sigma = exp(0.5 * ctx->tab(MTK_TAB_MODEL_LOGVAR64, t));
+    a.variance = ctx->tab(MTK_TAB_MODEL_VAR64, t);
+    a.grad = grad;
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
     a.z = z; a.z_idx = z_idx; a.noise = noise; a.noise_f64 = noise_is_f64; a.u = u;
     a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
@@ -1176,6 +1182,14 @@ extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step,
                        (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
+}
+
+extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
+                                 int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64,
+                                 const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed,
+                                 uint64_t row0, mtk_stream stream) {
+    return mtk_p_sample_step_guided(ctx, B, t, first_step, model_out, mo_rs, mo_cs, z, z_idx, noise, noise_is_f64, u, nullptr,
+                                    x_in_next, xi_rs, xi_cs, seed, row0, stream);
 }
 
 extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, double* z, int32_t* z_idx,

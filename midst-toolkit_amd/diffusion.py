@@ -100,7 +100,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         self.posterior_mean_coef1 = post["posterior_mean_coef1"].to(device)
         self.posterior_mean_coef2 = post["posterior_mean_coef2"].to(device)
         self._host_tables = {k: v.float() for k, v in buffers.items()}
-        self._host_tables.update({k: post[k] for k in ("posterior_mean_coef1", "posterior_mean_coef2", "model_log_variance")})
+        self._host_tables.update({k: post[k] for k in ("posterior_mean_coef1", "posterior_mean_coef2", "model_log_variance", "model_variance")})
         for key, value in buffers.items():
             self.register_buffer(key, value.float().to(device))
 
@@ -229,18 +229,17 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return lm.mean(), lg.mean()
 
     # ------------------------------------------------------------------ reverse chain
-    @torch.no_grad()
-    def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
-               conditioning_function=None, _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
-        """GMD:1370.  Returns ([B, Nn + C] fp64 on CPU, {"y": labels})."""
-        if conditioning_function is not None:
-            raise NotImplementedError("classifier guidance (conditional sampling, SURVEY section 8f rank 2) is not on the MI355X path yet")
+    def _reverse_chain(self, B: int, outputs: dict[str, Tensor], model_kwargs, conditioning_function, inj: dict | None) -> Tensor:
+        """The loop shared by sample (GMD:1403-1424) and conditional_sample (GMD:1344-1367): T x (denoiser,
+        mtk_p_sample_step[_guided]) on a device-resident fp64 state, then decode.  ``conditioning_function(features,
+        timestep, **model_kwargs)`` is the caller's (GMD:614): it sees the current numeric state as the reference's
+        would (fp32 on the first step, fp64 after) and returns d log p(y|x)/dx, which the step kernel folds into the mean."""
         eng = self.engine()
         dev = eng.device
-        B, Nn, C, D, S, T = batch_size, eng.Nn, eng.C, eng.D, eng.S, self.num_timesteps
-        inj = _injected
+        Nn, C, D, T = eng.Nn, eng.C, eng.D, self.num_timesteps
         philox = self.rng == "philox" and inj is None
         seed = int(torch.randint(1, 2**62, (1,)).item()) if philox else 0
+        model_kwargs = model_kwargs or {}
 
         def draw_u():
             return torch.cat([torch.rand((B, int(k)), device=dev, dtype=torch.float32) for k in self.num_classes], dim=1)
@@ -256,14 +255,9 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         x_in = torch.empty((D, B), dtype=torch.float32, device=dev)
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
         eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed)
-        if inj is not None and "y" in inj:
-            target = inj["y"]
-        else:
-            target = torch.multinomial(target_dist, num_samples=B, replacement=True)
-        outputs = {"y": target.long().to(dev)}
         for i, t in enumerate(reversed(range(T))):
             self._denoise_cm(eng, x_in, t, B, out)
-            n = u = None
+            n = u = grad = None
             if inj is not None:
                 n = inj["noise"][i] if Nn else None
                 u = inj["u"][i] if C else None
@@ -271,10 +265,41 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                 if Nn:
                     n = torch.randn((B, Nn), device=dev, dtype=torch.float32 if i == 0 else torch.float64)
                 u = draw_u() if C else None
-            eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed)
+            if conditioning_function is not None and Nn:
+                feats = z[:Nn].t().contiguous()
+                if i == 0:
+                    feats = feats.float()
+                tvec = torch.full((B,), t, device=dev, dtype=torch.long)
+                grad = conditioning_function(feats, tvec, **model_kwargs).detach().to(device=dev, dtype=torch.float32).contiguous()
+            eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed, grad=grad)
         sample = torch.empty((B, Nn + C), dtype=torch.float64, device=dev)
         eng.sample_decode(B, z, z_idx, sample)
-        return sample.cpu(), outputs
+        return sample.cpu()
+
+    @torch.no_grad()
+    def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
+               conditioning_function=None, _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+        """GMD:1370.  Returns ([B, Nn + C] fp64 on CPU, {"y": labels}).  ``conditioning_function``: classifier guidance
+        of the numeric features (gaussian_p_sample GMD:699-702)."""
+        dev = self.engine().device
+        if _injected is not None and "y" in _injected:
+            target = _injected["y"]
+        else:
+            target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
+        outputs = {"y": target.long().to(dev)}
+        return self._reverse_chain(batch_size, outputs, model_kwargs, conditioning_function, _injected), outputs
+
+    def conditional_sample(self, targets: Tensor, model_kwargs: dict[str, Any] | None = None, conditioning_function=None,
+                           _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+        """GMD:1319.  The reference's loop never draws an initial categorical state (``log_z`` stays ``[B, 0]``), so it
+        only runs on numeric-only tables — the multi-table pipeline's case (SYNTH:385-423); the same restriction here."""
+        if self._has_cat:
+            raise ValueError("conditional_sample: the reference's loop (GMD:1344) has no initial categorical state; "
+                             "it is only defined for num_classes = [0]")
+        with torch.no_grad():
+            dev = self.engine().device
+            outputs = {"y": targets.long().to(dev)}
+            return self._reverse_chain(len(targets), outputs, model_kwargs, conditioning_function, _injected), outputs
 
     def sample_all(self, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False,
                    model_kwargs: dict[str, Any] | None = None, conditioning_function=None) -> tuple[Tensor, Tensor]:

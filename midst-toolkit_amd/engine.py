@@ -128,12 +128,15 @@ class Engine:
             check(_lib.lib().mtk_sample_init(self._h, B, ptr(z0), ptr(u0), ptr(z), ptr(z_idx), ptr(x_in), xi_strides[0], xi_strides[1],
                                              seed, row0, self._stream()))
 
-    def p_sample_step(self, B, t, first, model_out, mo_strides, z, z_idx, noise, u, x_in_next, xi_strides, seed=0, row0=0):
+    def p_sample_step(self, B, t, first, model_out, mo_strides, z, z_idx, noise, u, x_in_next, xi_strides, seed=0, row0=0, grad=None):
+        """``grad``: optional [B, Nn] fp32 contiguous classifier-guidance gradient (condition_mean, GMD:585)."""
         nf64 = int(noise is not None and noise.dtype == torch.float64)
+        if grad is not None and (grad.dtype != torch.float32 or not grad.is_contiguous() or tuple(grad.shape) != (B, self.Nn)):
+            raise ValueError(f"guidance gradient must be a contiguous fp32 [{B}, {self.Nn}] tensor, got {tuple(grad.shape)} {grad.dtype}")
         with torch.cuda.device(self.device):
-            check(_lib.lib().mtk_p_sample_step(self._h, B, int(t), int(first), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z),
-                                               ptr(z_idx), ptr(noise), nf64, ptr(u), ptr(x_in_next), xi_strides[0], xi_strides[1],
-                                               seed, row0, self._stream()))
+            check(_lib.lib().mtk_p_sample_step_guided(self._h, B, int(t), int(first), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z),
+                                                      ptr(z_idx), ptr(noise), nf64, ptr(u), ptr(grad), ptr(x_in_next), xi_strides[0],
+                                                      xi_strides[1], seed, row0, self._stream()))
 
     def sample_decode(self, B, z, z_idx, out):
         with torch.cuda.device(self.device):

@@ -346,15 +346,19 @@ def tf_score(s: Schedule, Nn: int, params, x: torch.Tensor, noise: torch.Tensor,
 
 
 # --------------------------------------------------------------------------- reverse chain (a16-a18)
-def gaussian_p_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor):
+def gaussian_p_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor,
+                    grad: torch.Tensor | None = None):
     """a16 / GMD:358-429, 663-705.  ``z`` is fp32 on the first step and fp64 afterwards (finding 0.4);
     dtype promotion is left to torch exactly as in the reference (per-row gathered, dimensioned
-    coefficient tensors — a 0-dim fp64 coefficient would NOT promote an fp32 ``noise``)."""
+    coefficient tensors — a 0-dim fp64 coefficient would NOT promote an fp32 ``noise``).
+    ``grad``: what the caller's conditioning function returned for ``z`` (condition_mean, GMD:585-615)."""
     tt = torch.full((z.shape[0],), t, dtype=torch.long)
     col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731  (DU:172 extract)
     x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat
     mean = col(s.posterior_mean_coef1) * x0_hat + col(s.posterior_mean_coef2) * z
     mask = (tt != 0).float().view(-1, 1)
+    if grad is not None:  # GMD:614-615: the mean is cut to fp32, the fp64 variance promotes the sum again
+        mean = mean.float() + col(s.model_variance_f64) * grad.float()
     return mean + mask * torch.exp(0.5 * col(s.model_log_variance_f64)) * noise
 
 
@@ -366,9 +370,11 @@ def multinomial_p_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tenso
 
 
 def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us,
-                 mlp_dtype: torch.dtype = torch.float32):
+                 mlp_dtype: torch.dtype = torch.float32, conditioning_function=None, model_kwargs=None):
     """a18 / GMD:1370-1424 with injected randomness.  ``noises[i]``/``us[i]`` belong to the i-th
-    executed step (t = T-1-i).  Returns [B, Nn+C] fp64 (numeric then category codes)."""
+    executed step (t = T-1-i).  Returns [B, Nn+C] fp64 (numeric then category codes).
+    ``conditioning_function(features, timestep, **model_kwargs)``: classifier guidance (GMD:699-702); with
+    K = [0] and u0 = None this is also conditional_sample (GMD:1319-1367), whose state starts the same way."""
     C = 0 if (len(K) == 0 or int(K[0]) == 0) else len(K)
     z = z0
     B = z0.shape[0]
@@ -378,7 +384,8 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
     for i, t in enumerate(reversed(range(s.T))):
         tt = torch.full((B,), t, dtype=torch.long)
         out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype)
-        z = gaussian_p_step(s, out[:, :Nn], z, t, noises[i])
+        grad = conditioning_function(z, tt, **(model_kwargs or {})) if conditioning_function is not None else None
+        z = gaussian_p_step(s, out[:, :Nn], z, t, noises[i], grad)
         if C:
             z_idx = multinomial_p_step(s, K, out[:, Nn:], z_idx, t, us[i])
     return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z

@@ -38,3 +38,23 @@ def tt(a, dtype=None) -> torch.Tensor:
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a, b = a.double(), b.double()
     return float(((a - b).abs() / b.abs().clamp_min(1e-6)).max()) if a.numel() else 0.0
+
+
+def load_guided(tag: str = "A_numeric") -> dict:
+    """Fixture of tools/make_golden.py::gen_guided: the reference's conditional_sample ("cs") and guided sample ("sg")."""
+    with np.load(os.path.join(GOLDEN, f"guided_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    d["Nn"], d["T"], d["scale"] = int(d["Nn"]), int(d["T"]), float(d["scale"])
+    d["d_layers"] = [int(v) for v in d["d_layers"]]
+    d["params"] = {k[2:]: tt(v) for k, v in d.items() if k.startswith("w_")}
+    return d
+
+
+def guidance_function(centers: torch.Tensor, scale: float, T: int):
+    """The closed-form stand-in for the classifier gradient that generated the guided fixture (same formula as
+    tools/make_golden.py::guidance_function); device-agnostic."""
+    def conditioning_function(features, timestep, **kwargs):
+        y = kwargs["y"].view(-1).long().to(features.device)
+        x = features.detach().float()
+        return (centers.to(features.device)[y] - x) * (scale * (1.0 + timestep.float()[:, None] / T))
+    return conditioning_function

@@ -254,6 +254,61 @@ def test_full_chain(tag):
         close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=max(1e-5, 3 * own))
 
 
+@pytest.mark.parametrize("which", ["cs", "sg"])
+def test_guided_chains(which):
+    """conditional_sample (GMD:1319) and sample(..., conditioning_function) with the reference's own draws injected,
+    against the reference's outputs (tests/golden/guided_A_numeric.npz) — same bar as test_full_chain.  The
+    conditioning function runs on the device tensors the chain hands it, like the classifier gradient of SYNTH:429."""
+    import midst_toolkit_amd as mtk
+    from tests.helpers import guidance_function, load_guided
+
+    g = load_guided()
+    Nn, T = g["Nn"], g["T"]
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(g["d_layers"], 0.0))
+    net.load_state_dict(g["params"], strict=True)
+    d = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev()).to(dev())
+    cond = guidance_function(tt(g["centers"]), g["scale"], T)
+    targets = tt(g["targets"])
+    noise = [tt(n).to(dev()) for n in g[f"{which}_noise"]]
+    noise[0] = noise[0].float()
+    inj = {"z0": tt(g[f"{which}_z0"]).to(dev()), "noise": noise}
+    seen = []
+
+    def spy(features, timestep, **kw):
+        seen.append((features.dtype, tuple(features.shape), features.is_cuda, int(timestep[0])))
+        return cond(features, timestep, **kw)
+
+    if which == "cs":
+        got, outs = d.conditional_sample(targets, model_kwargs={"y": targets}, conditioning_function=spy, _injected=inj)
+        assert torch.equal(outs["y"].cpu(), targets.long())
+    else:
+        inj["y"] = tt(g["sg_y"])
+        got, outs = d.sample(targets.shape[0], torch.ones(3), model_kwargs={"y": targets}, conditioning_function=spy, _injected=inj)
+        assert torch.equal(outs["y"].cpu(), tt(g["sg_y"]).long())
+    # the callback saw what the reference's would: [B, Nn] on the device, fp32 at t = T-1 and fp64 after, t descending
+    assert [s_[3] for s_ in seen] == list(reversed(range(T)))
+    assert seen[0][0] == torch.float32 and all(s_[0] == torch.float64 for s_ in seen[1:])
+    assert all(s_[1] == (targets.shape[0], Nn) and s_[2] for s_ in seen)
+    want = tt(g[f"{which}_sample"])
+    assert got.dtype == torch.float64 and got.shape == want.shape and not got.is_cuda
+    s = orc.make_schedule(T, "cosine")
+    cpu_noise = [n.cpu() for n in noise]
+    ref64 = orc.sample_chain(s, np.array([0]), Nn, g["params"], inj["z0"].cpu(), None, cpu_noise, [None] * T, mlp_dtype=torch.float64,
+                             conditioning_function=cond, model_kwargs={"y": targets})
+    own = float((ref64 - want).abs().max())
+    close(got, want, rtol=RTOL, atol=max(1e-5, 3 * own))
+    # and guidance does something: the unguided chain from the same draws lands elsewhere
+    plain, _ = d.sample(targets.shape[0], torch.ones(3), _injected=dict(inj, y=torch.zeros(targets.shape[0], dtype=torch.long)))
+    assert float((plain - want).abs().max()) > 1e-2
+
+
+def test_conditional_sample_rejects_categorical_tables():
+    c = load_case("B_ragged")
+    d = build(c, T=4)
+    with pytest.raises(ValueError):
+        d.conditional_sample(torch.zeros((4, 1), dtype=torch.long))
+
+
 def test_sample_all_and_philox_mode():
     c = load_case("B_ragged")
     d = build(c, T=12)

@@ -113,6 +113,24 @@ def test_full_chain_bit_exact(tag):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("which", ["cs", "sg"])
+def test_guided_chains_bit_exact(which):
+    """conditional_sample (GMD:1319) and sample(..., conditioning_function) (GMD:1370, condition_mean GMD:585) of the
+    reference, every draw injected: the oracle reproduces both bit for bit."""
+    from tests.helpers import guidance_function, load_guided
+
+    d = load_guided()
+    s = orc.make_schedule(d["T"], "cosine")
+    cond = guidance_function(tt(d["centers"]), d["scale"], d["T"])
+    noises = [tt(n) for n in d[f"{which}_noise"]]
+    noises[0] = noises[0].float()
+    got = orc.sample_chain(s, np.array([0]), d["Nn"], d["params"], tt(d[f"{which}_z0"]), None, noises, [None] * len(noises),
+                           conditioning_function=cond, model_kwargs={"y": tt(d["targets"])})
+    want = tt(d[f"{which}_sample"])
+    assert got.dtype == want.dtype == torch.float64
+    assert torch.equal(got, want)
+
+
 def test_scan_recurrence_equals_logcumsumexp():
     """The scalar fp64 recurrence the HIP kernel implements == torch's block LSE, bit for bit."""
     g = torch.Generator().manual_seed(7)

@@ -296,9 +296,59 @@ def gen_train(tag, K, Nn, d_layers, T, B, steps, lr, wd, n_rows=99):
     print(f"train {tag}: losses {losses[0]} -> {losses[-1]}")
 
 
+def guidance_function(centers: torch.Tensor, scale: float, T: int):
+    """A closed-form stand-in for the classifier gradient of SYNTH:429-451 (same call signature and dtype): the
+    gradient of log N(features; centers[y], I) scaled by a factor that grows with t."""
+    def conditioning_function(features, timestep, **kwargs):
+        y = kwargs["y"].view(-1).long()
+        x = features.detach().float()
+        return (centers[y] - x) * (scale * (1.0 + timestep.float()[:, None] / T))
+    return conditioning_function
+
+
+def gen_guided(tag, Nn, d_layers, T_chain, B, n_classes=3, scale=0.35):
+    """conditional_sample (GMD:1319) and sample(..., conditioning_function) (GMD:1370) of the reference with every
+    draw captured; numeric-only table, as in the multi-table pipeline that uses them."""
+    diff, params = build([0], Nn, d_layers, T_chain)
+    g = torch.Generator().manual_seed(99)
+    centers = torch.randn((n_classes, Nn), generator=g)
+    targets = torch.randint(0, n_classes, (B, 1), generator=g)
+    cond = guidance_function(centers, scale, T_chain)
+    out = {"Nn": np.array(Nn), "d_layers": np.array(d_layers), "T": np.array(T_chain), "centers": centers.numpy(),
+           "scale": np.array(scale), "targets": targets.numpy()}
+    out.update({f"w_{k}": v.numpy() for k, v in params.items()})
+    for name in ("cs", "sg"):
+        log: list = []
+        torch.manual_seed(777 if name == "cs" else 778)
+        with capture_rng(log):
+            if name == "cs":
+                with torch.no_grad():
+                    smp, _ = diff.conditional_sample(targets, model_kwargs={"y": targets}, conditioning_function=cond)
+            else:
+                smp, outs = diff.sample(B, torch.ones(n_classes), model_kwargs={"y": targets}, conditioning_function=cond)
+        kinds = [e[0] for e in log]
+        assert kinds[0] == "randn"
+        pos = 1
+        if name == "sg":
+            assert kinds[pos] == "multinomial"
+            out["sg_y"] = outs["y"].numpy()
+            pos += 1
+        assert kinds[pos:] == ["randn_like"] * T_chain, kinds
+        out[f"{name}_z0"] = log[0][1].numpy()
+        out[f"{name}_noise"] = np.stack([e[1].double().numpy() for e in log[pos:]])
+        out[f"{name}_sample"] = smp.numpy()
+        assert smp.dtype == torch.float64
+    np.savez_compressed(os.path.join(OUT, f"guided_{tag}.npz"), **out)
+    print(f"guided {tag}: B={B} Nn={Nn} T={T_chain}")
+
+
 def main():
+    if "--guided-only" in sys.argv:
+        gen_guided("A_numeric", 8, [64, 64], 12, 48)
+        return
     if "--train-only" not in sys.argv:
         main_cases()
+        gen_guided("A_numeric", 8, [64, 64], 12, 48)
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
