@@ -1,4 +1,5 @@
 """midst_toolkit_amd — MI355X-native diffusion hot path of midst-toolkit (drop-in classes)."""
+from .data import FastTensorDataLoader, endless  # noqa: F401
 from .diffusion import (  # noqa: F401
     FoundNaNsError,
     GaussianLossType,

@@ -91,3 +91,26 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_fast_tensor_dataloader_matches_reference_batches():
+    """Same batch boundaries and, for the same torch seed, the same permutations as the reference's
+    FastTensorDataLoader over two shuffled epochs (tests/golden/loader.npz, tools/make_golden.py::gen_loader)."""
+    import itertools
+
+    import numpy as np
+    from midst_toolkit_amd.data import FastTensorDataLoader, endless
+    from tests.helpers import GOLDEN
+
+    with np.load(os.path.join(GOLDEN, "loader.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    torch.manual_seed(2024)
+    dl = FastTensorDataLoader([x, y], batch_size=8, shuffle=True)
+    assert len(dl) == int(g["n_batches"])
+    got = list(itertools.islice(endless(dl), int(g["count"])))
+    for k, (bx, by) in enumerate(got):
+        assert torch.equal(bx, torch.from_numpy(g[f"b{k}_x"])) and torch.equal(by, torch.from_numpy(g[f"b{k}_y"]))
+    # unshuffled: plain slices, ragged tail kept
+    plain = list(FastTensorDataLoader([x, y], batch_size=16))
+    assert [b[0].shape[0] for b in plain] == [16, 16, 5] and torch.equal(torch.cat([b[1] for b in plain]), y)

@@ -342,13 +342,37 @@ def gen_guided(tag, Nn, d_layers, T_chain, B, n_classes=3, scale=0.35):
     print(f"guided {tag}: B={B} Nn={Nn} T={T_chain}")
 
 
+def gen_loader():
+    """Batches of the reference's FastTensorDataLoader over two shuffled epochs (data_loaders.py:486-551)."""
+    from midst_toolkit.models.clavaddpm.data_loaders import FastTensorDataLoader
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((37, 3), generator=g)
+    y = torch.arange(37).float()
+    torch.manual_seed(2024)
+    dl = FastTensorDataLoader([x, y], batch_size=8, shuffle=True)
+    out = {"x": x.numpy(), "y": y.numpy(), "n_batches": np.array(len(dl))}
+    k = 0
+    for _ in range(2):
+        for bx, by in dl:
+            out[f"b{k}_x"], out[f"b{k}_y"] = bx.numpy(), by.numpy()
+            k += 1
+    out["count"] = np.array(k)
+    np.savez_compressed(os.path.join(OUT, "loader.npz"), **out)
+    print("loader:", k, "batches")
+
+
 def main():
+    if "--loader-only" in sys.argv:
+        gen_loader()
+        return
     if "--guided-only" in sys.argv:
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         return
     if "--train-only" not in sys.argv:
         main_cases()
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
+        gen_loader()
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
