@@ -59,7 +59,9 @@ enum mtk_table {
     MTK_TAB_POST_COEF2 = 9,     /* posterior_mean_coef2           GMD:228-230 */
     MTK_TAB_MODEL_LOGVAR64 = 10, /* log([posterior_variance[1], (1-alphas)[1:]]) in fp64, GMD:387-394 */
     MTK_TAB_MODEL_VAR64 = 11,   /* [posterior_variance[1], (1-alphas)[1:]] in fp64 (the "variance" of GMD:425, used by condition_mean GMD:615) */
-    MTK_NTAB = 12
+    MTK_TAB_ACP = 12,           /* alphas_cumprod                 GMD:260 */
+    MTK_TAB_ACP_PREV = 13,      /* alphas_cumprod_prev            GMD:261 (DDIM, GMD:1106-1107, 1240-1241) */
+    MTK_NTAB = 14
 };
 
 /* Denoiser arithmetic. */
@@ -163,6 +165,15 @@ int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int first_step, con
                              int64_t mo_cs, double* z, int32_t* z_idx, const void* noise, int noise_is_f64, const float* u,
                              const float* grad, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0,
                              mtk_stream stream);
+
+/* Replaces one iteration of sample_ddim's loop (GMD:1292-1308) after the denoiser call: gaussian_ddim_step (GMD:1070-1118)
+ * and multinomial_ddim_step (GMD:1211-1257) with eta = 0, the only value sample_ddim passes (no noise term; the
+ * categorical mixture keeps the x0 and the uniform branch).  Same state buffers as mtk_p_sample_step; the numeric state
+ * stays fp32-representable (the reference's DDIM chain is fp32 throughout).  u: [B, S] row-major or NULL -> Philox.
+ * Score-based guidance (condition_score, GMD:617-661) is not implemented. */
+int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
+                  int32_t* z_idx, const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0,
+                  mtk_stream stream);
 
 /* Replaces the initial draw of sample() (GMD:1392-1399): z0 [B, Nn] row-major fp32 (or NULL → Philox)
  * into the fp64 state z [Nn][B]; categories by Gumbel-argmax of uniform logits from u0 [B, S]

@@ -366,6 +366,67 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
     }
 }
 
+// One DDIM step with eta = 0, the only value sample_ddim (GMD:1259-1316) ever passes: gaussian_ddim_step (GMD:1070-1118)
+// and multinomial_ddim_step (GMD:1211-1257).  Everything stays fp32 in the reference (no fp64 table is involved), so the
+// state — kept in the fp64 buffer of the ancestral chain — holds fp32-representable values and all arithmetic is fp32 in
+// the reference's operation order.  sigma = 0: the noise term vanishes, coef1 = 0 puts -inf on the "stay" branch of the
+// categorical mixture, which leaves logsumexp(log(abp) + log_x0, log(1 - abp) - log K).
+struct DdimArgs {
+    DevTables d;
+    int64_t B;
+    int t;
+    float sqrt_recip, sqrt_recipm1, c_x0, c_eps, log_c2, log_c3;  // c_x0 = sqrt(abp), c_eps = sqrt(1 - abp); logs of coef2 / coef3
+    const float* mo; int64_t mo_rs, mo_cs;
+    double* z;
+    int32_t* z_idx;
+    const float* u;
+    float* x_in; int64_t xi_rs, xi_cs;
+    uint64_t seed, row0;
+};
+
+__global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
+    const Staged s = stage_tables<false>(a.d);
+    const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
+    const uint32_t stream_u = MTK_STREAM_STEP + 2u * (uint32_t)a.t + 1u;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const float* mo = a.mo + row * a.mo_rs;
+        float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
+        PhiloxU pu(a.seed, a.row0 + row, stream_u);
+        for (int j = 0; j < Nn; ++j) {
+            double* zp = a.z + (int64_t)j * a.B + row;
+            const float zf = (float)*zp, eh = mo[j * a.mo_cs];
+            const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;       // GMD:545 _predict_features_start_from_eps
+            const float eps = (a.sqrt_recip * zf - x0h) / a.sqrt_recipm1;    // GMD:580-583
+            const float zn = x0h * a.c_x0 + a.c_eps * eps;                   // GMD:1114, sigma = 0
+            *zp = (double)zn;
+            if (xo) xo[j * a.xi_cs] = zn;
+        }
+        for (int k = 0; k < C; ++k) {
+            const int o = s.off[k], Kk = s.off[k + 1] - o;
+            const float cc = a.log_c3 - s.logK[k];
+            const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+            float mx = -INFINITY;
+            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
+            float sum = 0.0f;
+            for (int i = 0; i < Kk; ++i) sum += expf(mc[i * a.mo_cs] - mx);
+            const float lsum = logf(sum);
+            float best = -INFINITY;
+            int arg = 0;
+            for (int i = 0; i < Kk; ++i) {
+                const float b = a.log_c2 + ((mc[i * a.mo_cs] - mx) - lsum);  // log(coef2) + log_softmax (GMD:761)
+                const float m = fmaxf(b, cc);
+                const float logp = (m == -INFINITY) ? m : m + logf(expf(b - m) + expf(cc - m));  // torch.logsumexp over (-inf, b, cc)
+                const float g = a.u ? gumbel(a.u[row * S + o + i]) : gumbel_fast(pu.uniform(o + i));
+                const float v = g + logp;
+                if (v > best || i == 0) { best = v; arg = i; }
+            }
+            a.z_idx[(int64_t)k * a.B + row] = arg;
+            if (xo)
+                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
+    }
+}
+
 // sample() prologue (GMD:1392-1399)
 struct InitArgs {
     DevTables d;
@@ -1190,6 +1251,33 @@ extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step,
                                  uint64_t row0, mtk_stream stream) {
     return mtk_p_sample_step_guided(ctx, B, t, first_step, model_out, mo_rs, mo_cs, z, z_idx, noise, noise_is_f64, u, nullptr,
                                     x_in_next, xi_rs, xi_cs, seed, row0, stream);
+}
+
+extern "C" int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
+                             int32_t* z_idx, const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed,
+                             uint64_t row0, mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: null context");
+    if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: t = %d outside [0, %d)", t, ctx->T);
+    if (B < 0 || !model_out || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: null pointer or negative B");
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    DdimArgs a;
+    a.d = ctx->dev();
+    a.B = B; a.t = t;
+    a.sqrt_recip = (float)ctx->tab(MTK_TAB_SQRT_RECIP_ACP, t);
+    a.sqrt_recipm1 = (float)ctx->tab(MTK_TAB_SQRT_RECIPM1_ACP, t);
+    const float abp = (float)ctx->tab(MTK_TAB_ACP_PREV, t);
+    const float coef3 = (1.0f - 0.0f) - abp;  // 1 - coef1 - coef2 with sigma = 0 (GMD:1243-1245)
+    a.c_x0 = sqrtf(abp);
+    a.c_eps = sqrtf((1.0f - abp) - 0.0f);
+    a.log_c2 = logf(abp);
+    a.log_c3 = coef3 > 0.0f ? logf(coef3) : -INFINITY;
+    a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
+    a.z = z; a.z_idx = z_idx; a.u = u;
+    a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
+    hipLaunchKernelGGL(k_ddim_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
 }
 
 extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, double* z, int32_t* z_idx,

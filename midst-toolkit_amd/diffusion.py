@@ -229,7 +229,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return lm.mean(), lg.mean()
 
     # ------------------------------------------------------------------ reverse chain
-    def _reverse_chain(self, B: int, outputs: dict[str, Tensor], model_kwargs, conditioning_function, inj: dict | None) -> Tensor:
+    def _reverse_chain(self, B: int, outputs: dict[str, Tensor], model_kwargs, conditioning_function, inj: dict | None,
+                       ddim: bool = False) -> Tensor:
         """The loop shared by sample (GMD:1403-1424) and conditional_sample (GMD:1344-1367): T x (denoiser,
         mtk_p_sample_step[_guided]) on a device-resident fp64 state, then decode.  ``conditioning_function(features,
         timestep, **model_kwargs)`` is the caller's (GMD:614): it sees the current numeric state as the reference's
@@ -259,12 +260,15 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             self._denoise_cm(eng, x_in, t, B, out)
             n = u = grad = None
             if inj is not None:
-                n = inj["noise"][i] if Nn else None
+                n = inj["noise"][i] if Nn and not ddim else None
                 u = inj["u"][i] if C else None
             elif not philox:
-                if Nn:
+                if Nn and not ddim:
                     n = torch.randn((B, Nn), device=dev, dtype=torch.float32 if i == 0 else torch.float64)
                 u = draw_u() if C else None
+            if ddim:  # GMD:1292-1308, eta = 0: no Gaussian noise enters (the reference draws it and multiplies by sigma = 0)
+                eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed)
+                continue
             if conditioning_function is not None and Nn:
                 feats = z[:Nn].t().contiguous()
                 if i == 0:
@@ -274,7 +278,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed, grad=grad)
         sample = torch.empty((B, Nn + C), dtype=torch.float64, device=dev)
         eng.sample_decode(B, z, z_idx, sample)
-        return sample.cpu()
+        return sample.float().cpu() if ddim else sample.cpu()  # the reference's DDIM chain is fp32 end to end
 
     @torch.no_grad()
     def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
@@ -288,6 +292,20 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
         outputs = {"y": target.long().to(dev)}
         return self._reverse_chain(batch_size, outputs, model_kwargs, conditioning_function, _injected), outputs
+
+    @torch.no_grad()
+    def sample_ddim(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
+                    conditioning_function=None, _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+        """GMD:1259 (eta = 0).  Returns ([B, Nn + C] fp32 on CPU, {"y": labels})."""
+        if conditioning_function is not None:
+            raise NotImplementedError("score-based guidance of the DDIM chain (condition_score, GMD:617-661) is not on the MI355X path")
+        dev = self.engine().device
+        if _injected is not None and "y" in _injected:
+            target = _injected["y"]
+        else:
+            target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
+        outputs = {"y": target.long().to(dev)}
+        return self._reverse_chain(batch_size, outputs, model_kwargs, None, _injected, ddim=True), outputs
 
     def conditional_sample(self, targets: Tensor, model_kwargs: dict[str, Any] | None = None, conditioning_function=None,
                            _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
@@ -304,12 +322,11 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
     def sample_all(self, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False,
                    model_kwargs: dict[str, Any] | None = None, conditioning_function=None) -> tuple[Tensor, Tensor]:
         """GMD:1426."""
-        if ddim:
-            raise NotImplementedError("DDIM sampling (SURVEY section 8f rank 4) is not on the MI355X path")
         all_targets, all_samples = [], []
         num_generated = 0
         while num_generated < num_samples:
-            sample, outputs = self.sample(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function)
+            sample_fn = self.sample_ddim if ddim else self.sample  # GMD:1452-1455
+            sample, outputs = sample_fn(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function)
             mask_nan = torch.any(sample.isnan(), dim=1)
             sample = sample[~mask_nan]
             outputs["y"] = outputs["y"].cpu()[~mask_nan]

@@ -138,6 +138,11 @@ class Engine:
                                                       ptr(z_idx), ptr(noise), nf64, ptr(u), ptr(grad), ptr(x_in_next), xi_strides[0],
                                                       xi_strides[1], seed, row0, self._stream()))
 
+    def ddim_step(self, B, t, model_out, mo_strides, z, z_idx, u, x_in_next, xi_strides, seed=0, row0=0):
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_ddim_step(self._h, B, int(t), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z), ptr(z_idx), ptr(u),
+                                           ptr(x_in_next), xi_strides[0], xi_strides[1], seed, row0, self._stream()))
+
     def sample_decode(self, B, z, z_idx, out):
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_sample_decode(self._h, B, ptr(z), ptr(z_idx), ptr(out), self._stream()))

@@ -391,6 +391,53 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
     return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z
 
 
+# --------------------------------------------------------------------------- DDIM (section 8f rank 4)
+def gaussian_ddim_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor, eta: float = 0.0):
+    """GMD:1070-1118 (no conditioning): every table involved is fp32, so an fp32 state stays fp32."""
+    tt = torch.full((z.shape[0],), t, dtype=torch.long)
+    col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731
+    x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat  # GMD:545
+    eps = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)    # GMD:580-583
+    ab, abp = col(s.alphas_cumprod), col(s.alphas_cumprod_prev)
+    sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+    mean_pred = x0_hat * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma**2) * eps
+    mask = (tt != 0).float().view(-1, 1)
+    return mean_pred + mask * sigma * noise
+
+
+def multinomial_ddim_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tensor, t: int, u: torch.Tensor, eta: float = 0.0):
+    """GMD:1211-1257: mixture of "stay", the predicted x0 and uniform, then Gumbel-argmax."""
+    tt = torch.full((z_idx.shape[0],), t, dtype=torch.long)
+    log_z = log_onehot(z_idx, K)
+    log_x0 = block_log_softmax(out_cat, K)
+    col = lambda tab: tab[tt][:, None].expand(log_z.shape)  # noqa: E731
+    ab, abp = col(s.alphas_cumprod), col(s.alphas_cumprod_prev)
+    sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+    coef1 = sigma
+    coef2 = abp - sigma * ab
+    coef3 = 1 - coef1 - coef2
+    log_ps = torch.stack([torch.log(coef1) + log_z, torch.log(coef2) + log_x0, torch.log(coef3) - log_k_expanded(K)], dim=2)
+    return gumbel_argmax(torch.logsumexp(log_ps, dim=2), u, K)
+
+
+def sample_chain_ddim(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us,
+                      mlp_dtype: torch.dtype = torch.float32):
+    """sample_ddim (GMD:1259-1316) with injected randomness; returns [B, Nn+C] fp32."""
+    C = 0 if (len(K) == 0 or int(K[0]) == 0) else len(K)
+    z = z0
+    B = z0.shape[0]
+    z_idx = torch.zeros((B, 0), dtype=torch.int64)
+    if C:
+        z_idx = gumbel_argmax(torch.zeros((B, int(offsets_of(K)[-1]))), u0, K)
+    for i, t in enumerate(reversed(range(s.T))):
+        tt = torch.full((B,), t, dtype=torch.long)
+        out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype).float()
+        z = gaussian_ddim_step(s, out[:, :Nn], z, t, noises[i])
+        if C:
+            z_idx = multinomial_ddim_step(s, K, out[:, Nn:], z_idx, t, us[i])
+    return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z
+
+
 # --------------------------------------------------------------------------- conditioning of a11
 def multinomial_loss_floor(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0: torch.Tensor, xt_idx: torch.Tensor,
                            t: torch.Tensor, ulp: float = 2.0 ** -23) -> torch.Tensor:

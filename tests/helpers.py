@@ -58,3 +58,16 @@ def guidance_function(centers: torch.Tensor, scale: float, T: int):
         x = features.detach().float()
         return (centers.to(features.device)[y] - x) * (scale * (1.0 + timestep.float()[:, None] / T))
     return conditioning_function
+
+
+def load_ddim(tag: str) -> dict:
+    """Fixture of tools/make_golden.py::gen_ddim: the reference's sample_ddim with every draw captured."""
+    with np.load(os.path.join(GOLDEN, f"ddim_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    d["K"] = d["K"].astype(np.int64)
+    d["Nn"], d["T"], d["sched"] = int(d["Nn"]), int(d["T"]), str(d["sched"])
+    d["d_layers"] = [int(v) for v in d["d_layers"]]
+    d["C"] = len(d["K"]) if int(d["K"][0]) != 0 else 0
+    d["S"] = int(d["K"].sum())
+    d["D"] = d["Nn"] + d["S"]
+    return d

@@ -302,6 +302,40 @@ def test_guided_chains(which):
     assert float((plain - want).abs().max()) > 1e-2
 
 
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged"])
+def test_ddim_chain(tag):
+    """sample_ddim (GMD:1259, eta = 0) with the reference's draws injected against the reference's output
+    (tests/golden/ddim_*.npz; the oracle reproduces it bit for bit): the whole-chain bar of test_full_chain."""
+    from tests.helpers import load_ddim
+
+    c = load_ddim(tag)
+    Nn, C, T, B = c["Nn"], c["C"], c["T"], c["z0"].shape[0]
+    d = build(c, T=T)
+    inj = {"z0": tt(c["z0"]).to(dev()), "noise": [None] * T, "y": torch.zeros(B, dtype=torch.long)}
+    if C:
+        inj["u0"] = tt(c["u0"]).to(dev())
+        inj["u"] = [tt(v).to(dev()) for v in c["u"]]
+    got, _ = d.sample_ddim(B, torch.ones(1), _injected=inj)
+    want = tt(c["sample"])
+    assert got.dtype == torch.float32 and got.shape == want.shape and not got.is_cuda
+    same = (got[:, Nn:] == want[:, Nn:]).all(dim=1) if C else torch.ones(B, dtype=torch.bool)
+    assert float(same.float().mean()) >= 0.97, float(same.float().mean())
+    s = orc.make_schedule(T, c["sched"])
+    us = [tt(v) for v in c["u"]] if C else [None] * T
+    ref64 = orc.sample_chain_ddim(s, c["K"], Nn, case_params(c), tt(c["z0"]), tt(c["u0"]) if C else None, [tt(n) for n in c["noise"]], us,
+                                  mlp_dtype=torch.float64)
+    agree = same & ((ref64[:, Nn:] == want[:, Nn:]).all(dim=1) if C else same)
+    own = float((ref64[agree][:, :Nn] - want[agree][:, :Nn]).abs().max())
+    close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=max(1e-5, 3 * own))
+    # sample_all(ddim=True) routes here (GMD:1452)
+    torch.manual_seed(1)
+    x, y = d.sample_all(40, 32, torch.ones(1), ddim=True)
+    assert x.shape == (40, Nn + C) and x.dtype == torch.float32 and y.shape == (40,) and not bool(x.isnan().any())
+    if C:
+        codes = x[:, Nn:]
+        assert bool((codes == codes.round()).all()) and bool((codes >= 0).all()) and bool((codes < torch.tensor(c["K"]).float()).all())
+
+
 def test_conditional_sample_rejects_categorical_tables():
     c = load_case("B_ragged")
     d = build(c, T=4)

@@ -131,6 +131,21 @@ def test_guided_chains_bit_exact(which):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged"])
+def test_ddim_chain_bit_exact(tag):
+    """sample_ddim (GMD:1259-1316, eta = 0) of the reference, every draw injected: bit for bit, fp32 throughout."""
+    from tests.helpers import load_ddim
+
+    c = load_ddim(tag)
+    s = orc.make_schedule(c["T"], c["sched"])
+    us = [tt(v) for v in c["u"]] if c["C"] else [None] * c["T"]
+    got = orc.sample_chain_ddim(s, c["K"], c["Nn"], case_params(c), tt(c["z0"]), tt(c["u0"]) if c["C"] else None,
+                                [tt(n) for n in c["noise"]], us)
+    want = tt(c["sample"])
+    assert got.dtype == want.dtype == torch.float32
+    assert torch.equal(got, want)
+
+
 def test_scan_recurrence_equals_logcumsumexp():
     """The scalar fp64 recurrence the HIP kernel implements == torch's block LSE, bit for bit."""
     g = torch.Generator().manual_seed(7)

@@ -342,6 +342,43 @@ def gen_guided(tag, Nn, d_layers, T_chain, B, n_classes=3, scale=0.35):
     print(f"guided {tag}: B={B} Nn={Nn} T={T_chain}")
 
 
+def gen_ddim(tag, K, Nn, d_layers, T_chain, B, sched="cosine"):
+    """sample_ddim (GMD:1259) of the reference with every draw captured."""
+    K = np.asarray(K, dtype=np.int64)
+    C = len(K) if has_cat(K) else 0
+    diff, _ = build(K, Nn, d_layers, T_chain, sched)
+    log: list = []
+    torch.manual_seed(5150)
+    with capture_rng(log):
+        smp, outs = diff.sample_ddim(B, torch.ones(1))
+    kinds = [e[0] for e in log]
+    assert kinds[0] == "randn"
+    out = {"K": K, "Nn": np.array(Nn), "d_layers": np.array(d_layers), "T": np.array(T_chain), "sched": np.array(sched),
+           "z0": log[0][1].numpy()}
+    pos = 1
+    if C:
+        out["u0"] = torch.cat([e[1] for e in log[pos:pos + C]], dim=1).numpy()
+        pos += C
+    assert kinds[pos] == "multinomial"
+    pos += 1
+    ns, uss = [], []
+    for i in range(T_chain):
+        assert kinds[pos] == "randn_like", (i, kinds[pos])
+        ns.append(log[pos][1].numpy())
+        pos += 1
+        if C:
+            uss.append(torch.cat([e[1] for e in log[pos:pos + C]], dim=1).numpy())
+            pos += C
+    assert pos == len(log)
+    out["noise"] = np.stack(ns)
+    if C:
+        out["u"] = np.stack(uss)
+    out["sample"] = smp.numpy()
+    out["sample_dtype"] = np.array(str(smp.dtype))
+    np.savez_compressed(os.path.join(OUT, f"ddim_{tag}.npz"), **out)
+    print(f"ddim {tag}: B={B} dtype={smp.dtype}")
+
+
 def gen_loader():
     """Batches of the reference's FastTensorDataLoader over two shuffled epochs (data_loaders.py:486-551)."""
     from midst_toolkit.models.clavaddpm.data_loaders import FastTensorDataLoader
@@ -366,6 +403,10 @@ def main():
     if "--loader-only" in sys.argv:
         gen_loader()
         return
+    if "--ddim-only" in sys.argv:
+        gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
+        gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
+        return
     if "--guided-only" in sys.argv:
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         return
@@ -373,6 +414,8 @@ def main():
         main_cases()
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         gen_loader()
+        gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
+        gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
