@@ -186,6 +186,16 @@ int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, d
 int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, double* sample,
                       mtk_stream stream);
 
+/* Replaces dataset.numerical_transform.inverse_transform of the synthesiser (models/clavaddpm/synthesizer.py:251-277)
+ * for the quantile normaliser the pipeline fits (common/dataset_transformations.py:57-66): scikit-learn 1.7.2
+ * QuantileTransformer._transform_col(inverse=True) per column - Phi(x) when output_normal != 0, numpy-style linear
+ * interpolation of quantiles [n_quantiles][n_columns] (row-major, the fitted quantiles_) over references
+ * [n_quantiles] (references_), and the BOUNDS_THRESHOLD overrides.  x, out: [B, n_columns] fp64 row-major with
+ * leading dimensions x_ld / out_ld (out may alias x); NaN stays NaN.  Needs no context: device is the HIP ordinal. */
+int mtk_quantile_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, const double* quantiles,
+                         const double* references, int n_quantiles, int output_normal, double* out, int64_t out_ld,
+                         mtk_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training iteration.  Replaces ClavaDDPMTrainer._train_step /
  * _anneal_learning_rate / update_ema (models/clavaddpm/trainer.py:58-94, 138-155).

@@ -14,6 +14,7 @@ hipcc $FLAGS -c mtk_capi.hip -o _build/mtk_capi.o & pids+=($!)
 hipcc $FLAGS -c mtk_mlp_f32.hip -o _build/mtk_mlp_f32.o & pids+=($!)
 hipcc $FLAGS -c mtk_mlp_bf16.hip -o _build/mtk_mlp_bf16.o & pids+=($!)
 hipcc $FLAGS -c mtk_mlp_bf16_layered.hip -o _build/mtk_mlp_bf16_layered.o & pids+=($!)
+hipcc $FLAGS -ffp-contract=off -c mtk_transform.hip -o _build/mtk_transform.o & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC _build/*.o -o ../libmtk_hip.so
 echo "built $(cd .. && pwd)/libmtk_hip.so"

@@ -522,3 +522,37 @@ def train_loop(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], batches
         ema_update(ema, p)
         hist.append([float(lm), float(lg)])
     return np.asarray(hist, dtype=np.float64), p, ema
+
+
+# --------------------------------------------------------------------------- inverse quantile normalisation (8f rank 3)
+QT_BOUNDS_THRESHOLD = 1e-7  # sklearn.preprocessing._data.BOUNDS_THRESHOLD
+
+
+def quantile_inverse(x: np.ndarray, quantiles: np.ndarray, references: np.ndarray, output_normal: bool = True) -> np.ndarray:
+    """``dataset.numerical_transform.inverse_transform`` for the quantile normaliser (models/clavaddpm/synthesizer.py:277;
+    fitted at common/dataset_transformations.py:70-83).  The arithmetic lives in scikit-learn 1.7.2
+    ``QuantileTransformer._transform_col(inverse=True)``: ``scipy.stats.norm.cdf`` (= ``scipy.special.ndtr``), the bound
+    masks taken on the uniform image, ``numpy.interp`` over ``references_``, then upper and lower overrides in that
+    order.  Pinned by tests/golden/quantile_*.npz, which hold sklearn's own outputs."""
+    from scipy.special import ndtr
+
+    x = np.array(x, dtype=np.float64, copy=True)
+    out = np.empty_like(x)
+    for c in range(x.shape[1]):
+        q = np.asarray(quantiles[:, c], dtype=np.float64)
+        col = x[:, c]
+        with np.errstate(invalid="ignore"):
+            if output_normal:
+                col = ndtr(col)
+                lower = col - QT_BOUNDS_THRESHOLD < 0.0
+                upper = col + QT_BOUNDS_THRESHOLD > 1.0
+            else:
+                lower = col == 0.0
+                upper = col == 1.0
+        finite = ~np.isnan(col)
+        res = col.copy()
+        res[finite] = np.interp(col[finite], references, q)
+        res[upper] = q[-1]
+        res[lower] = q[0]
+        out[:, c] = res
+    return out

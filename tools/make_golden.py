@@ -399,7 +399,40 @@ def gen_loader():
     print("loader:", k, "batches")
 
 
+def gen_quantile():
+    """The reference's own quantile normaliser (common/dataset_transformations.py:46-84, Normalization.QUANTILE) fitted
+    on its single-table asset (99 rows -> 10 quantiles) and on a 36,000-row synthetic split (-> 1000 quantiles); the
+    fixture holds the fitted tables, inputs in the normalised space (chain-like values, both bound regions, saturating values, NaN)
+    and the fitted object's inverse_transform of them (what synthesizer.py:277 computes)."""
+    import pandas as pd
+    from midst_toolkit.common.dataset_transformations import normalize
+    from midst_toolkit.common.enumerations import Normalization
+
+    g = np.random.default_rng(77)
+    csv = pd.read_csv("/root/reference/tests/integration/assets/single_table/train.csv")
+    small = csv.select_dtypes("number").to_numpy(dtype=np.float64)
+    big = np.stack([g.lognormal(3.0, 1.2, 36000), np.round(g.normal(0, 40, 36000)), g.integers(0, 7, 36000).astype(np.float64),
+                    g.exponential(2.0, 36000) * (g.random(36000) > 0.3), g.normal(1e6, 5e3, 36000)], axis=1)
+    for tag, train in (("small", small), ("big", big)):
+        _, qt = normalize({"train": train}, Normalization.QUANTILE, seed=0)
+        n = 4096
+        x = g.normal(0, 1.3, (n, train.shape[1]))
+        x[:64] = g.normal(0, 1, (64, train.shape[1])) * 0.02 + np.where(g.random((64, train.shape[1])) > 0.5, 5.2, -5.2)
+        x[64, :] = 40.0  # Phi saturates to exactly 1 / 0 (sklearn refuses infinities)
+        x[65, :] = -40.0
+        x[66, 0] = np.nan
+        x[67, :] = 0.0
+        x[68:100] = np.sign(x[68:100]) * (5.0 + 4.0 * g.random((32, train.shape[1])))
+        want = qt.inverse_transform(x.copy())
+        np.savez_compressed(os.path.join(OUT, f"quantile_{tag}.npz"), x=x, quantiles=qt.quantiles_, references=qt.references_,
+                            want=want, output_normal=np.array(int(qt.output_distribution == "normal")))
+        print(f"quantile {tag}: n_quantiles={qt.n_quantiles_} columns={train.shape[1]}")
+
+
 def main():
+    if "--quantile-only" in sys.argv:
+        gen_quantile()
+        return
     if "--loader-only" in sys.argv:
         gen_loader()
         return
@@ -414,6 +447,7 @@ def main():
         main_cases()
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         gen_loader()
+        gen_quantile()
         gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
         gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
