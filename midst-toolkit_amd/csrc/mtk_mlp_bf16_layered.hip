@@ -13,12 +13,16 @@
 // The tile size is set by the memory system: per 16-wide k-step a workgroup pulls 16 KB from L2 for 64 MFMAs
 // (32 B/clk/CU, half of what a 128 x 128 tile needs).  Both operands are row-major [rows][K] bf16, so a lane's 8
 // k-values are one 16-byte read.  L2 -> LDS by LDS-DMA into a double buffer: the next k-block lands during the
-// MFMAs, one barrier per k-block, no staging registers.
+// MFMAs, one barrier per k-block, no staging registers.  The kernel is persistent (one workgroup per CU walks its
+// tiles; the k-blocks of all of them form one DMA stream) and its epilogue issues no vector loads (bias through the
+// scalar cache into the accumulator init).
 //
-// Measured (2^20 records, 4x1024, MI355X): 8.6 ms = 830 TFLOP/s.  Ablation builds (-DDIAG_*; wrong results, timing
-// only): without the epilogue 6.1 ms, without the in-loop DMA 7.3 ms, without the MFMAs 8.1 ms — the output
-// write-back (workgroups run in lock step, so all 256 store their 128 KB tiles at once, with no MFMA behind it) is
-// the largest single cost; a persistent tile loop that drains tile i's stores under tile i+1's k-loop is the next step.
+// Measured (2^20 records, 4x1024, MI355X, same box): 8.0 ms = 890 TFLOP/s (round start 8.8 ms).  In-kernel stamps
+// (-DDIAG_STAMPS, tools/build_variant.sh), per 256 x 256 x 1024 tile: k-loop 30.5 us, epilogue 3.4 us (was 28.3 + 5.8
+// with sixteen load -> vmcnt(0) round trips per 32 rows in the epilogue: removing them moved the stores' drain into the
+// next k-loop instead of shortening the tile).  In the k-loop a wave waits 0.6 us per k-block (1.9 us) at the
+// vmcnt(0) + barrier for the next block's DMA: the loop is bound by DMA latency (~2 us, records come from HBM or the
+// Infinity Cache) with one 64 KB block in flight — LDS capacity, not MFMA rate (0.85 us per block), sets the pace.
 #include <math.h>
 #include <stdlib.h>
 
@@ -28,15 +32,28 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BT = 256, BK = 64;
+constexpr int kRowPad = 256;  // activation matrices are padded to the record tile
 constexpr int NT = 2, WN = NT * 32;  // a wave's tile: 128 records (4 MFMA tiles) x 64 features (2)
-constexpr int kTileBytes = BT * BK * 2, kBufBytes = 2 * kTileBytes;  // one operand tile 32 KB; records + weights 64 KB
-constexpr size_t kLdsBytes = 2 * kBufBytes;  // double buffer = 128 KB (the 64 KB output staging reuses it after the k-loop)
+constexpr int kStageBytes = 32 * WN * 2;  // per wave: 32 rows x 64 bf16 of output staging, 4 KB
+// Wave grid WR x (8 / WR), MW 32-record MFMA tiles per wave.  <2, 4> is the 256 x 256 tile of the hidden layers (record
+// tile 32 KB + weight tile 32 KB per k-block).  <4, 2> is a 256 x 128 tile for a narrow head (N <= 128: 32 KB + 16 KB):
+// no MFMAs spent on 128 padding columns, and still one tile per 256 records, so a 65,536-row pass fills all 256 CUs.
+template <int WR, int MW> struct Geo {
+    static constexpr int WC = 8 / WR, BM = WR * MW * 32, BN = WC * WN;
+    static constexpr int kTileX = BM * BK * 2, kTileW = BN * BK * 2, kBuf = kTileX + kTileW;
+    static constexpr int XCH = BM / 8, OPS = (BM + BN) / 8, OPW = OPS / 8;  // 8-row DMA pieces: of the record tile, in all, per wave
+};
+// k-block double buffer (128 KB / 160 KB) + output staging for the bf16 layers (32 KB; the fp32 head stores directly)
+template <bool OF32, int WR, int MW> constexpr size_t lds_bytes() { return 2 * Geo<WR, MW>::kBuf + (OF32 ? 0 : 8 * kStageBytes); }
 
 struct GemmB {
     int64_t M;       // valid rows (fp32 output only)
+    int64_t MT;      // row tiles (Mpad / BM)
     int N;           // valid output features (fp32 output only)
+    int nb_n;        // column tiles (Npad / BN)
     int Kpad;        // multiple of BK: extent of the bf16 operands
     const uint16_t* X; int64_t x_ld;   // bf16 [Mpad][x_ld]
     const uint16_t* W;                 // bf16 [Npad256][Kpad], zero padded
@@ -45,38 +62,30 @@ struct GemmB {
     int relu;
     // output: bf16 row-major [Mpad][y_rs] (OF32 = false) or fp32 with generic strides, bounds-checked (OF32 = true)
     void* Y; int64_t y_rs, y_cs;
+    unsigned long long* stamps;  // DIAG_STAMPS builds only
 };
 
 extern __shared__ __attribute__((aligned(16))) uint16_t gb_smem[];
 
-template <bool OF32>
+// Persistent: one workgroup per CU walks a list of output tiles, and the k-blocks of ALL its tiles form one stream
+// through the LDS double buffer — the DMA cursor runs two blocks ahead of the MFMAs across tile boundaries.  A tile's
+// epilogue (bias, ReLU, bf16 rounding, staging, stores) therefore runs with the next tile's first two k-blocks already
+// in flight, its stores drain under the next tile's MFMAs, and there is no per-tile launch / first-load latency.
+template <bool OF32, int WR, int MW>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
+    typedef Geo<WR, MW> G;
+    constexpr int kBufBytes = G::kBuf, kTileX = G::kTileX;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 2, wc = wid & 3, li = lane & 31, hh = lane >> 5;
-    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  The nb_n column tiles
-    // of one 256-record row tile get consecutive slots on ONE XCD, so the record tile is fetched from HBM once and
-    // the other column tiles hit that XCD's L2 (the weights, <= 2 MiB a layer, stay resident in every L2).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nb_n = (g.N + BT - 1) / BT;
-    const int64_t mblk = (int64_t)(slot / nb_n) * 8 + xcd;
-    if (mblk * BT >= g.M) return;
-    const int64_t m0 = mblk * BT;
-    const int n0 = (slot % nb_n) * BT;
+    const int wr = wid / G::WC, wc = wid % G::WC, li = lane & 31, hh = lane >> 5;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  Row tile mblk belongs to
+    // XCD mblk & 7; its nb_n column tiles are consecutive slots of that XCD's list, and the XCD's workgroups take the
+    // slots round-robin, so the column tiles of a record tile run at the same time on ONE XCD: the records come from
+    // HBM once (the weights, <= 2 MiB a layer, stay resident in every L2).
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, wstride = gridDim.x >> 3;
+    const int64_t slots = ((g.MT - xcd + 7) / 8) * g.nb_n;  // this XCD's tiles
+    if (wq >= slots) return;
+    const int nkb = g.Kpad / BK;
 
-    f32x16 acc[4][NT];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    // Operand tiles (256 rows x 64 bf16 = one 128-byte line per row, 32 KB) go L2 -> LDS by LDS-DMA, no registers
-    // involved: one wave-instruction moves 8 full lines (64 lanes x 16 B) into 1 KiB of LDS, 64 of them per k-block,
-    // 8 per wave.  The LDS image is linear in the lane, so the bank swizzle is applied on the GLOBAL side: LDS slot
-    // (r, cs) holds piece cs ^ ((r >> 1) & 7) of row r.  ds_read_b128 resolves banks over 256-byte rows (two tile rows)
-    // in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: each group reads 8 row PAIRS whose pair index
-    // is distinct mod 8, so with this key its 16 lanes land on the 16 different 16-byte slots (keyed on r & 7 instead,
-    // SQ_LDS_BANK_CONFLICT showed every read 2-way).
     const int wv = __builtin_amdgcn_readfirstlane(wid);
     const int lr = lane >> 3;
     unsigned voff_x[2], voff_w[2];  // [parity of the 8-row chunk]: the swizzle key (row >> 1) & 7 takes row bit 3 from it
@@ -86,18 +95,34 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         voff_x[par] = (unsigned)(lr * g.x_ld * 2 + lc * 16);
         voff_w[par] = (unsigned)(lr * g.Kpad * 2 + lc * 16);
     }
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(g.X + m0 * g.x_ld);
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(g.W + (int64_t)n0 * g.Kpad);
-    auto dma_ops = [&](int kb, int buf, int j0, int j1) {
-#ifdef DIAG_NODMA
-        if (kb > 1) return;
-#endif
+    // Operand tiles (256 rows x 64 bf16 = one 128-byte line per row, 32 KB) go L2 -> LDS by LDS-DMA, no registers
+    // involved: one wave-instruction moves 8 full lines (64 lanes x 16 B) into 1 KiB of LDS, 64 of them per k-block,
+    // 8 per wave.  The LDS image is linear in the lane, so the bank swizzle is applied on the GLOBAL side: LDS slot
+    // (r, cs) holds piece cs ^ ((r >> 1) & 7) of row r.  ds_read_b128 resolves banks over 256-byte rows (two tile rows)
+    // in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: each group reads 8 row PAIRS whose pair index
+    // is distinct mod 8, so with this key its 16 lanes land on the 16 different 16-byte slots (keyed on r & 7 instead,
+    // SQ_LDS_BANK_CONFLICT showed every read 2-way).
+    // DMA cursor: tile (d_slot) and k-block (d_kb) of the next block to request; d_cnt counts requested blocks (buffer parity)
+    int64_t d_slot = wq;
+    int d_kb = 0;
+    unsigned d_cnt = 0;
+    const unsigned char* d_xb = nullptr;
+    const unsigned char* d_wb = nullptr;
+    auto dma_tile = [&]() {  // operand base pointers of tile d_slot
+        const int64_t mblk = (d_slot / g.nb_n) * 8 + xcd;
+        const int n0 = (int)(d_slot % g.nb_n) * G::BN;
+        d_xb = reinterpret_cast<const unsigned char*>(g.X + mblk * G::BM * g.x_ld);
+        d_wb = reinterpret_cast<const unsigned char*>(g.W + (int64_t)n0 * g.Kpad);
+    };
+    auto dma_ops = [&](int j0, int j1) {  // pieces [j0, j1) of this wave's 8 of block (d_slot, d_kb)
+        if (d_slot >= slots) return;
+        const int buf = d_cnt & 1;
 #pragma unroll
         for (int j = j0; j < j1; ++j) {
-            const int o = wv * 8 + j, operand = o >> 5, chunk = o & 31;
-            const unsigned char* gp = (operand ? wb + (int64_t)chunk * 8 * g.Kpad * 2 : xb + (int64_t)chunk * 8 * g.x_ld * 2) + (int64_t)kb * BK * 2;
+            const int o = wv * G::OPW + j, operand = o >= G::XCH, chunk = operand ? o - G::XCH : o;
+            const unsigned char* gp = (operand ? d_wb + (int64_t)chunk * 8 * g.Kpad * 2 : d_xb + (int64_t)chunk * 8 * g.x_ld * 2) + (int64_t)d_kb * BK * 2;
             const unsigned voff = operand ? voff_w[chunk & 1] : voff_x[chunk & 1];
-            const unsigned dst = (unsigned)(buf * kBufBytes + operand * kTileBytes + chunk * 1024);
+            const unsigned dst = (unsigned)(buf * kBufBytes + operand * kTileX + chunk * 1024);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep)
@@ -105,33 +130,40 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                          : "memory");
         }
     };
+    auto dma_advance = [&]() {
+        if (d_slot >= slots) return;
+        ++d_cnt;
+        if (++d_kb == nkb) {
+            d_kb = 0;
+            d_slot += wstride;
+            if (d_slot < slots) dma_tile();
+        }
+    };
     const unsigned char* lds = reinterpret_cast<const unsigned char*>(gb_smem);
-    struct Frags { bf16x8 a[4], b[NT]; };
+    struct Frags { bf16x8 a[MW], b[NT]; };
     auto read_frags = [&](Frags& f, int buf, int ks) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ra = wr * 128 + q * 32 + li, kp = ks * 2 + hh;
+        for (int q = 0; q < MW; ++q) {
+            const int ra = (wr * MW + q) * 32 + li, kp = ks * 2 + hh;
             f.a[q] = *reinterpret_cast<const bf16x8*>(lds + buf * kBufBytes + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int rb = wc * WN + q * 32 + li, kp = ks * 2 + hh;
-            f.b[q] = *reinterpret_cast<const bf16x8*>(lds + buf * kBufBytes + kTileBytes + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
+            f.b[q] = *reinterpret_cast<const bf16x8*>(lds + buf * kBufBytes + kTileX + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
         }
     };
+
+    f32x16 acc[MW][NT];
     // A operand = weights (rows n), B operand = records: D[n][m], i.e. lane -> record, register -> feature
     auto mfma_row = [&](const Frags& f, int mt) {
-#ifdef DIAG_NOMFMA
-        asm volatile("" :: "v"(f.a[mt]), "v"(f.b[0]), "v"(f.b[1]));
-        return;
-#endif
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.b[nt], f.a[mt], acc[mt][nt], 0, 0, 0);
     };
     auto mfma_all = [&](const Frags& f) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) mfma_row(f, mt);
+        for (int mt = 0; mt < MW; ++mt) mfma_row(f, mt);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -139,94 +171,152 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     // the barrier sits BEFORE the last k-step's MFMAs, so the fragment reads that follow it (first k-step of the next
     // block) and the DMA issue (block after next, into the buffer just released) are covered by 16 MFMAs instead of
     // stalling the matrix pipe once per k-block.
-    const int nkb = g.Kpad / BK;
     Frags F0, F1;
-    dma_ops(0, 0, 0, 8);
+    dma_tile();
+    dma_ops(0, G::OPW);
+    dma_advance();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (nkb > 1) dma_ops(1, 1, 0, 8);
-    read_frags(F0, 0, 0);
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        read_frags(F1, buf, 1);
-        mfma_all(F0);
-        read_frags(F0, buf, 2);
-        mfma_all(F1);
-        read_frags(F1, buf, 3);
-        mfma_all(F0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // block kb+1 landed (this wave's share); F1 is in registers
-        __syncthreads();                                            // ... everyone's share, and buffer `buf` has no readers left
-        __builtin_amdgcn_sched_barrier(0);
-        const bool more = kb + 1 < nkb, more2 = kb + 2 < nkb;
-        if (more) read_frags(F0, buf ^ 1, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(F1, mt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more2) dma_ops(kb + 2, buf, 2 * mt, 2 * mt + 2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // C/D map with weights as the A operand: record (m) = lane & 31, feature n = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
-    // a lane holds 4 consecutive features per register quad.  fp32 output (head): stored directly through the generic
-    // strides.  bf16 output: the wave's 128 x 64 tile goes through LDS (free after the k-loop) in two 64-row halves so
-    // that it leaves as row-contiguous 16-byte pieces (128 B per row per wave) instead of 8-byte granules 2 KB apart.
-#ifdef DIAG_NOEPI
-    if (g.relu >= 0) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(g.Y)[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7]; return; }
+    dma_ops(0, G::OPW);
+    dma_advance();
+    unsigned c_cnt = 0;  // consumed blocks (buffer parity)
+#ifdef DIAG_STAMPS
+    unsigned long long st_k = 0, st_e = 0, st_w0 = 0, st_wn = 0, st_n = 0, st_a, st_b;
+#define STAMP(x) x = wall_clock64()
+#else
+#define STAMP(x)
 #endif
-    // Staging image per wave: 64 rows x 128 B, no padding; the 8-byte granule gi of row r sits at granule gi ^ (r & 15),
-    // so the lanes' ds_write_b64 (32 rows, same gi) and the ds_read_b128 of the copy-out both touch every bank once
-    // (a padded row stride of 144 B made the writes 4-way conflicted, a quarter of the kernel's time).
-    unsigned char* stage = reinterpret_cast<unsigned char*>(gb_smem) + wid * 64 * (WN * 2);  // 8 KB per wave
+    unsigned char* stage = reinterpret_cast<unsigned char*>(gb_smem) + 2 * kBufBytes + wid * kStageBytes;  // bf16 layers only
+    for (int64_t slot = wq; slot < slots; slot += wstride) {
+        const int64_t m0 = ((slot / g.nb_n) * 8 + xcd) * G::BM;
+        const int n0 = (int)(slot % g.nb_n) * G::BN;
+        // The accumulators start from the bias.  It comes through the SCALAR cache (the wave's 64 columns are uniform;
+        // a lane picks its half of each group of 8 by lane >> 5): vector loads here or in the epilogue would queue behind
+        // the DMA in flight and behind the previous tile's stores on vmcnt — the epilogue used to spend 5.8 of a tile's
+        // 34 us in sixteen load -> s_waitcnt vmcnt(0) round trips per 32 rows.
+        {
+            const float* bp = g.bias + n0 + (wv % G::WC) * WN;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int64_t row = m0 + wr * 128 + mt * 32 + li;
-        const int tr = g.emb ? ((g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar)) : 0;
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x8 b0, b1, b2, b3;
+                asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3)
+                             : "s"(bp + nt * 32)
+                             : "memory");
+                const f32x8 bq[4] = {b0, b1, b2, b3};
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl = nt * 32 + 8 * q + 4 * hh;  // feature inside the wave's 64
-                const int n = n0 + wc * WN + nl;
-                const float4 bq = *reinterpret_cast<const float4*>(g.bias + n);
-                float v[4] = {acc[mt][nt][4 * q] + bq.x, acc[mt][nt][4 * q + 1] + bq.y, acc[mt][nt][4 * q + 2] + bq.z,
-                              acc[mt][nt][4 * q + 3] + bq.w};
-                if (g.emb && n < g.emb_ld) {
-                    const float4 eq = *reinterpret_cast<const float4*>(g.emb + (int64_t)tr * g.emb_ld + n);
-                    v[0] += eq.x; v[1] += eq.y; v[2] += eq.z; v[3] += eq.w;
-                }
-                if (g.relu) {
+                    for (int j = 0; j < 4; ++j) {
+                        const float bv = hh ? bq[q][4 + j] : bq[q][j];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-                }
-                if (OF32) {
-                    float* yf = reinterpret_cast<float*>(g.Y);
-                    if (row < g.M) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (n + j < g.N) yf[row * g.y_rs + (int64_t)(n + j) * g.y_cs] = v[j];
+                        for (int a = 0; a < MW; ++a) acc[a][nt][4 * q + j] = bv;
                     }
-                } else {
-                    __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    *reinterpret_cast<uint2*>(stage + ((mt & 1) * 32 + li) * (WN * 2) + (((nl >> 2) ^ (li & 15)) * 8)) = *reinterpret_cast<const uint2*>(e);
+            }
+        }
+        STAMP(st_a);
+        read_frags(F0, c_cnt & 1, 0);
+        for (int kb = 0; kb < nkb; ++kb, ++c_cnt) {
+            const int buf = c_cnt & 1;
+            read_frags(F1, buf, 1);
+            mfma_all(F0);
+            read_frags(F0, buf, 2);
+            mfma_all(F1);
+            read_frags(F1, buf, 3);
+            mfma_all(F0);
+            STAMP(st_b);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // next block landed (this wave's share); F1 is in registers
+            __syncthreads();                                            // ... everyone's share, and buffer `buf` has no readers left
+#ifdef DIAG_STAMPS
+            { const unsigned long long now = wall_clock64(); if (kb == 0) st_w0 += now - st_b; else st_wn += now - st_b; }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) read_frags(F0, buf ^ 1, 0);
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(F1, mt);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_ops(mt * G::OPW / MW, (mt + 1) * G::OPW / MW);  // block after next (possibly of the next tile) into the buffer just released
+            }
+            dma_advance();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+#ifdef DIAG_STAMPS
+        STAMP(st_b); st_k += st_b - st_a; ++st_n;
+#endif
+        // C/D map with weights as the A operand: record (m) = lane & 31, feature n = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+        // a lane holds 4 consecutive features per register quad.  fp32 output (head): stored directly through the generic
+        // strides.  bf16 output: the wave's 128 x 64 tile goes through its own 4 KB of LDS in four 32-row pieces so that it
+        // leaves as row-contiguous 16-byte pieces (128 B per row per wave) instead of 8-byte granules 2 KB apart.
+        // Staging image: 32 rows x 128 B, no padding; the 8-byte granule gi of row r sits at granule gi ^ (r & 15), so
+        // the lanes' ds_write_b64 (32 rows, same gi) and the ds_read_b128 of the copy-out both touch every bank once
+        // (a padded row stride of 144 B made the writes 4-way conflicted, a quarter of the kernel's time).  LDS
+        // operations of one wave execute in order, so the piece needs no barrier.
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            const int64_t row = m0 + (wr * MW + mt) * 32 + li;
+            float4 eq[NT * 4];  // time-embedding row of the record (first layer only): all eight loads in flight together
+            if (g.emb) {
+                const int tr = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
+#pragma unroll
+                for (int i = 0; i < NT * 4; ++i) {
+                    const int n = n0 + wc * WN + (i >> 2) * 32 + 8 * (i & 3) + 4 * hh;
+                    eq[i] = n < g.emb_ld ? *reinterpret_cast<const float4*>(g.emb + (int64_t)tr * g.emb_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = nt * 32 + 8 * q + 4 * hh;  // feature inside the wave's 64
+                    const int n = n0 + wc * WN + nl;
+                    float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                    if (g.emb) {
+                        const float4 e4 = eq[nt * 4 + q];
+                        v[0] += e4.x; v[1] += e4.y; v[2] += e4.z; v[3] += e4.w;
+                    }
+                    if (g.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                    }
+                    if (OF32) {
+                        float* yf = reinterpret_cast<float*>(g.Y);
+                        if (row < g.M) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (n + j < g.N) yf[row * g.y_rs + (int64_t)(n + j) * g.y_cs] = v[j];
+                        }
+                    } else {
+                        __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<uint2*>(stage + li * (WN * 2) + (((nl >> 2) ^ (li & 15)) * 8)) = *reinterpret_cast<const uint2*>(e);
+                    }
+                }
+            }
+            if (!OF32) {  // rows [wr * 128 + mt * 32, + 32) of the wave are staged: 256 pieces of 16 B, 4 per lane
+                uint16_t* yb = reinterpret_cast<uint16_t*>(g.Y);
+#pragma unroll
+                for (int i = 0; i < WN / 16; ++i) {
+                    const int pce = lane + 64 * i, r = pce / (WN / 8), c8 = (pce % (WN / 8)) * 8;
+                    uint4 val = *reinterpret_cast<const uint4*>(stage + r * (WN * 2) + (((c8 >> 3) ^ ((r & 15) >> 1)) * 16));
+                    if (r & 1) val = make_uint4(val.z, val.w, val.x, val.y);  // odd key: the pair's two granules are swapped
+                    *reinterpret_cast<uint4*>(yb + (m0 + (wr * MW + mt) * 32 + r) * g.y_rs + n0 + wc * WN + c8) = val;
                 }
             }
         }
-        if (!OF32 && (mt & 1)) {  // rows [wr * 128 + (mt - 1) * 32, + 64) of the wave are staged: 512 pieces, 8 per lane
-            uint16_t* yb = reinterpret_cast<uint16_t*>(g.Y);
-#pragma unroll
-            for (int i = 0; i < WN / 8; ++i) {
-                const int pce = lane + 64 * i, r = pce / (WN / 8), c8 = (pce % (WN / 8)) * 8;
-                uint4 val = *reinterpret_cast<const uint4*>(stage + r * (WN * 2) + (((c8 >> 3) ^ ((r & 15) >> 1)) * 16));
-                if (r & 1) val = make_uint4(val.z, val.w, val.x, val.y);  // odd key: the pair's two granules are swapped
-                *reinterpret_cast<uint4*>(yb + (m0 + wr * 128 + (mt - 1) * 32 + r) * g.y_rs + n0 + wc * WN + c8) = val;
-            }
-        }
+#ifdef DIAG_STAMPS
+        STAMP(st_a); st_e += st_a - st_b;
+#endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DIAG_STAMPS
+    if (tid == 0 && g.stamps) {
+        atomicAdd(g.stamps + 0, st_k); atomicAdd(g.stamps + 1, st_e); atomicAdd(g.stamps + 2, st_w0); atomicAdd(g.stamps + 3, st_wn);
+        atomicAdd(g.stamps + 4, st_n); atomicAdd(g.stamps + 5, st_n * (unsigned long long)nkb);
+    }
+#endif
 }
 
 __global__ void k_to_bf16_pad(uint16_t* dst, int rows_pad, int cols_pad, const float* src, int src_ld, int rows, int cols) {
@@ -240,37 +330,83 @@ __global__ void k_to_bf16_pad(uint16_t* dst, int rows_pad, int cols_pad, const f
 __global__ void k_pad_f32(float* dst, int n_pad, const float* src, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) dst[i] = i < n ? src[i] : 0.0f;
 }
-// the denoiser input (fp32, generic strides, B rows x D columns) as a zero-padded bf16 [Mpad][ld] matrix: one thread
-// converts 8 consecutive columns of one row (one 16-byte store); consecutive threads take consecutive rows, the
-// contiguous direction of the column-major intermediates
-__global__ void k_x_to_bf16(uint16_t* dst, int ld, int64_t Mpad, const float* x, int64_t x_rs, int64_t x_cs, int64_t M, int D) {
-    const int64_t n = Mpad * (ld / 8);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i / Mpad);
-        const int64_t r = i - (int64_t)cg * Mpad;
-        __bf16 e[8];
+// The denoiser input (fp32, generic strides, B rows x D columns) as a zero-padded bf16 [Mpad][ld] matrix.  A workgroup
+// converts 64 rows x 128 columns through LDS: it reads along whichever direction of the source is contiguous (lanes
+// over rows for the column-major intermediates, over columns for the row-major tensors of the drop-in API) and writes
+// whole 256-byte rows of the destination (a thread per 8 columns wrote 16-byte pieces 256 B apart: 2 TB/s).
+__global__ __launch_bounds__(256) void k_x_to_bf16(uint16_t* dst, int ld, const float* x, int64_t x_rs, int64_t x_cs, int64_t M, int D) {
+    __shared__ uint32_t tile[64 * 65];  // [row][column pair], odd row stride: conflict-free both ways
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int col0 = blockIdx.y * 128;
+    const bool along_cols = x_cs == 1;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int r = along_cols ? (t >> 6) + 4 * i : (t & 63);
+        const int cp = along_cols ? (t & 63) : (t >> 6) + 4 * i;
+        const int64_t row = row0 + r;
+        const int c = col0 + 2 * cp;
+        const bool ok0 = row < M && c < D, ok1 = row < M && c + 1 < D;
+        const float v0 = x[(ok0 ? row : 0) * x_rs + (int64_t)(ok0 ? c : 0) * x_cs];
+        const float v1 = x[(ok1 ? row : 0) * x_rs + (int64_t)(ok1 ? c + 1 : 0) * x_cs];
+        const __bf16 e[2] = {(__bf16)(ok0 ? v0 : 0.0f), (__bf16)(ok1 ? v1 : 0.0f)};
+        tile[r * 65 + cp] = *reinterpret_cast<const uint32_t*>(e);
+    }
+    __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            const bool ok = r < M && c < D;
-            const float v = x[(ok ? r : 0) * x_rs + (int64_t)(ok ? c : 0) * x_cs];
-            e[j] = (__bf16)(ok ? v : 0.0f);
+    for (int i = 0; i < 4; ++i) {
+        const int pc = t + 256 * i, r = pc >> 4, c8 = pc & 15;
+        if (col0 + c8 * 8 < ld) {
+            const uint32_t* q = tile + r * 65 + c8 * 4;
+            *reinterpret_cast<uint4*>(dst + (row0 + r) * ld + col0 + c8 * 8) = make_uint4(q[0], q[1], q[2], q[3]);
         }
-        *reinterpret_cast<uint4*>(dst + r * ld + cg * 8) = *reinterpret_cast<const uint4*>(e);
     }
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <bool OF32>
-int launch(const GemmB& g, int64_t Mpad, int Npad, hipStream_t s) {
+int n_cus_layered(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    int n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
+    if (device >= 0 && device < 64) cached[device] = n;
+    return n;
+}
+
+template <bool OF32, int WR, int MW>
+int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
+    typedef Geo<WR, MW> G;
+    constexpr size_t lds = lds_bytes<OF32, WR, MW>();
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32, WR, MW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((k_gemm_bf16<OF32>), dim3((unsigned)(((Mpad / BT + 7) / 8) * 8 * (Npad / BT))), dim3(512), kLdsBytes, s, g);
+    if (Mpad % G::BM || Npad % G::BN) MTK_FAIL(MTK_ERR_STATE, "layered bf16 GEMM: %lld x %d is not a multiple of the %d x %d tile", (long long)Mpad, Npad, G::BM, G::BN);
+    g.MT = Mpad / G::BM;
+    g.nb_n = Npad / G::BN;
+    // one workgroup per CU (160 KB of LDS each); per XCD no more workgroups than its longest tile list
+    int64_t per_xcd = n_cus_layered(device) / 8;
+    if (per_xcd < 1) per_xcd = 1;
+    const int64_t most = ((g.MT + 7) / 8) * g.nb_n;
+    if (most < per_xcd) per_xcd = most;
+#ifdef DIAG_STAMPS
+    static unsigned long long* d_st = nullptr;
+    if (!d_st) MTK_HIP(hipMalloc(&d_st, 64));
+    MTK_HIP(hipMemsetAsync(d_st, 0, 64, s));
+    g.stamps = d_st;
+#endif
+    hipLaunchKernelGGL((k_gemm_bf16<OF32, WR, MW>), dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, g);
     MTK_HIP(hipGetLastError());
+#ifdef DIAG_STAMPS
+    MTK_HIP(hipStreamSynchronize(s));
+    unsigned long long h[8];
+    MTK_HIP(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
+    const double n = h[4] ? (double)h[4] : 1.0;
+    fprintf(stderr, "[layered stamps] K=%d N=%d tiles=%llu per tile (10 ns ticks): k-loop %.0f epilogue %.0f first-wait %.1f other-waits(avg each) %.1f\n", g.Kpad,
+            g.nb_n * G::BN, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] > h[4] ? (double)h[3] / (double)(h[5] - h[4]) : 0.0);
+#endif
     return MTK_OK;
 }
 
@@ -313,11 +449,19 @@ int mtk_pack_layered(mtk_ctx* c, hipStream_t s) {
 int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                              float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
     if (c->wb16.size() != c->blocks.size() + 2) MTK_FAIL(MTK_ERR_STATE, "layered bf16 denoiser: weights are not packed");
-    static const int64_t chunk = [] { const char* e = getenv("MTK_LAYERED_CHUNK"); return e ? (int64_t)atol(e) : (int64_t)(1 << 17); }();
     int maxld = round_up(c->proj.in_pad, BK);  // widest bf16 activation row (input included)
     if (round_up(c->proj.out_pad, BT) > maxld) maxld = round_up(c->proj.out_pad, BT);
     for (auto& l : c->blocks) maxld = round_up(l.out_pad, BT) > maxld ? round_up(l.out_pad, BT) : maxld;
-    const int64_t need_rows = (B < chunk ? (B + BT - 1) / BT * BT : chunk);
+    // Rows per pass through the layer chain: a layer's input and output (2 x rows x maxld bf16) should fit the 256 MB
+    // Infinity Cache, so that what one layer writes the next reads from there and not from HBM (4x1024, 2^20 records:
+    // 8.7 ms at 131,072 rows a pass, 8.1 ms at 65,536; below 32,768 the six launches per pass dominate).
+    static const int64_t chunk_env = [] { const char* e = getenv("MTK_LAYERED_CHUNK"); return e ? (int64_t)atol(e) : (int64_t)0; }();
+    int64_t chunk = (chunk_env + kRowPad - 1) / kRowPad * kRowPad;
+    if (chunk <= 0) {
+        chunk = 32768;
+        while (chunk < 262144 && 2 * chunk * (int64_t)maxld * 4 <= ((int64_t)256 << 20)) chunk *= 2;
+    }
+    const int64_t need_rows = (B < chunk ? (B + kRowPad - 1) / kRowPad * kRowPad : chunk);
     const size_t need = (size_t)need_rows * maxld;
     if (need > c->ws16_elems) {
         MTK_HIP(hipStreamSynchronize(s));
@@ -331,11 +475,11 @@ int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs
     uint16_t* ws[2] = {reinterpret_cast<uint16_t*>(c->ws16[0]), reinterpret_cast<uint16_t*>(c->ws16[1])};
     for (int64_t r0 = 0; r0 < B; r0 += chunk) {
         const int64_t M = (B - r0 < chunk) ? B - r0 : chunk;
-        const int64_t Mpad = (M + BT - 1) / BT * BT;
+        const int64_t Mpad = (M + kRowPad - 1) / kRowPad * kRowPad;
         int rc;
         // input -> bf16 [Mpad][kp0]
         const int kp0 = round_up(c->proj.in_pad, BK);
-        hipLaunchKernelGGL(k_x_to_bf16, dim3(2048), dim3(256), 0, s, ws[0], kp0, Mpad, x + r0 * x_rs, x_rs, x_cs, M, c->D);
+        hipLaunchKernelGGL(k_x_to_bf16, dim3((unsigned)(Mpad / 64), (unsigned)((kp0 + 127) / 128)), dim3(256), 0, s, ws[0], kp0, x + r0 * x_rs, x_rs, x_cs, M, c->D);
         MTK_HIP(hipGetLastError());
         int cur = 0;
         GemmB g{};
@@ -345,7 +489,7 @@ int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs
         g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar;
         int ld = round_up(c->proj.out_pad, BT);
         g.Y = ws[cur ^ 1]; g.y_rs = ld;
-        if ((rc = launch<false>(g, Mpad, ld, s))) return rc;
+        if ((rc = launch<false, 2, 4>(g, c->device, Mpad, ld, s))) return rc;
         cur ^= 1;
         for (size_t i = 0; i < c->blocks.size(); ++i) {
             const MlpLayer& l = c->blocks[i];
@@ -355,7 +499,7 @@ int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs
             h.W = reinterpret_cast<const uint16_t*>(c->wb16[1 + i]); h.bias = c->bb16[1 + i]; h.relu = 1;
             ld = round_up(l.out_pad, BT);
             h.Y = ws[cur ^ 1]; h.y_rs = ld;
-            if ((rc = launch<false>(h, Mpad, ld, s))) return rc;
+            if ((rc = launch<false, 2, 4>(h, c->device, Mpad, ld, s))) return rc;
             cur ^= 1;
         }
         GemmB h{};
@@ -363,7 +507,9 @@ int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs
         h.X = ws[cur]; h.x_ld = ld;
         h.W = reinterpret_cast<const uint16_t*>(c->wb16.back()); h.bias = c->bb16.back();
         h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
-        if ((rc = launch<true>(h, Mpad, round_up(c->head.out_pad, BT), s))) return rc;
+        if (c->head.out <= 128) rc = launch<true, 4, 2>(h, c->device, Mpad, 128, s);
+        else rc = launch<true, 2, 4>(h, c->device, Mpad, round_up(c->head.out_pad, BT), s);
+        if (rc) return rc;
     }
     return MTK_OK;
 }

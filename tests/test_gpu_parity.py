@@ -447,6 +447,38 @@ def test_mlp_forward_bf16_layered(shape):
     assert torch.equal(o2.t().contiguous(), out)
 
 
+@pytest.mark.parametrize("shape", [(120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512])])
+def test_mlp_forward_bf16_layered_many_tiles(shape):
+    """The layered GEMM is persistent: a workgroup streams the k-blocks of several output tiles through one LDS double
+    buffer.  70,001 rows give every workgroup 4-5 tiles (and, with D = 142, an odd number of k-blocks per tile, so the
+    buffer parity flips from tile to tile).  A row's result does not depend on the batch it sits in: windows of the big
+    batch must equal separate small calls bit for bit (those are checked against the oracle above), and a sample of
+    rows is checked against the oracle directly."""
+    import midst_toolkit_amd as mtk
+
+    D, layers = shape
+    params = orc.init_mlp_params(D, layers, seed=3)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(layers), 0.0)).to(dev())
+    net.load_state_dict(params, strict=True)
+    net.precision = "bf16"
+    g = torch.Generator().manual_seed(2)
+    B = 70_001
+    x = torch.randn((B, D), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    xd, td = x.to(dev()), t.to(dev())
+    with torch.no_grad():
+        out = net(xd, td)
+    assert bool(torch.isfinite(out).all())
+    eng = net.engine(dev())
+    for lo in (0, 256 * 97 + 13, 65_536 - 150, B - 300):
+        o = eng.mlp_forward(xd[lo:lo + 300].contiguous(), td[lo:lo + 300].contiguous(), precision="bf16")
+        assert torch.equal(o, out[lo:lo + 300]), lo
+    pick = torch.randperm(B, generator=g)[:1500]
+    want = orc.mlp_forward(params, x[pick], t[pick])
+    scale = float(want.abs().max())
+    assert float((out.cpu()[pick] - want).abs().max()) <= BF16_TOL * scale
+
+
 def bf16_emulated_forward(params, x, t):
     """fp32 math on bf16-rounded weights and activations (what the fused kernel computes, up to
     summation order)."""
