@@ -44,10 +44,12 @@ constexpr int kStageBytes = 32 * WN * 2;  // per wave: 32 rows x 64 bf16 of outp
 template <int WR, int MW> struct Geo {
     static constexpr int WC = 8 / WR, BM = WR * MW * 32, BN = WC * WN;
     static constexpr int kTileX = BM * BK * 2, kTileW = BN * BK * 2, kBuf = kTileX + kTileW;
-    static constexpr int XCH = BM / 8, OPS = (BM + BN) / 8, OPW = OPS / 8;  // 8-row DMA pieces: of the record tile, in all, per wave
+    static constexpr int XPW = BM / 64, WPW = BN / 64, OPW = XPW + WPW;  // 8-row, 1 KiB DMA pieces per wave and k-block: records, weights
+    static_assert(WR != 2 || kTileW == 8 * kStageBytes, "the output staging of a bf16 tile borrows one weight buffer");
 };
-// k-block double buffer (128 KB / 160 KB) + output staging for the bf16 layers (32 KB; the fp32 head stores directly)
-template <bool OF32, int WR, int MW> constexpr size_t lds_bytes() { return 2 * Geo<WR, MW>::kBuf + (OF32 ? 0 : 8 * kStageBytes); }
+// THREE record buffers and two weight buffers (96 + 64 KB = 160 KB for the hidden layers): records are the long-latency
+// operand (HBM / Infinity Cache, ~2 us), weights hit the L2, so the record stream runs one k-block further ahead.
+template <int WR, int MW> constexpr size_t lds_bytes() { return 3 * Geo<WR, MW>::kTileX + 2 * Geo<WR, MW>::kTileW; }
 
 struct GemmB {
     int64_t M;       // valid rows (fp32 output only)
@@ -68,13 +70,13 @@ struct GemmB {
 extern __shared__ __attribute__((aligned(16))) uint16_t gb_smem[];
 
 // Persistent: one workgroup per CU walks a list of output tiles, and the k-blocks of ALL its tiles form one stream
-// through the LDS double buffer — the DMA cursor runs two blocks ahead of the MFMAs across tile boundaries.  A tile's
-// epilogue (bias, ReLU, bf16 rounding, staging, stores) therefore runs with the next tile's first two k-blocks already
-// in flight, its stores drain under the next tile's MFMAs, and there is no per-tile launch / first-load latency.
+// through the LDS buffers — the weight cursor runs two blocks ahead of the MFMAs, the record cursor three, across tile
+// boundaries.  A tile's epilogue (ReLU, bf16 rounding, staging, stores) therefore runs with the next tile's first blocks
+// already in flight, its stores drain under the next tile's MFMAs, and there is no per-tile launch / first-load latency.
 template <bool OF32, int WR, int MW>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     typedef Geo<WR, MW> G;
-    constexpr int kBufBytes = G::kBuf, kTileX = G::kTileX;
+    constexpr int kTileX = G::kTileX, kTileW = G::kTileW, kWBase = 3 * G::kTileX;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / G::WC, wc = wid % G::WC, li = lane & 31, hh = lane >> 5;
     // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, each with its own L2.  Row tile mblk belongs to
@@ -96,61 +98,64 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         voff_w[par] = (unsigned)(lr * g.Kpad * 2 + lc * 16);
     }
     // Operand tiles (256 rows x 64 bf16 = one 128-byte line per row, 32 KB) go L2 -> LDS by LDS-DMA, no registers
-    // involved: one wave-instruction moves 8 full lines (64 lanes x 16 B) into 1 KiB of LDS, 64 of them per k-block,
-    // 8 per wave.  The LDS image is linear in the lane, so the bank swizzle is applied on the GLOBAL side: LDS slot
+    // involved: one wave-instruction moves 8 full lines (64 lanes x 16 B) into 1 KiB of LDS, 4 + 4 of them per wave and
+    // k-block.  The LDS image is linear in the lane, so the bank swizzle is applied on the GLOBAL side: LDS slot
     // (r, cs) holds piece cs ^ ((r >> 1) & 7) of row r.  ds_read_b128 resolves banks over 256-byte rows (two tile rows)
     // in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: each group reads 8 row PAIRS whose pair index
     // is distinct mod 8, so with this key its 16 lanes land on the 16 different 16-byte slots (keyed on r & 7 instead,
     // SQ_LDS_BANK_CONFLICT showed every read 2-way).
-    // DMA cursor: tile (d_slot) and k-block (d_kb) of the next block to request; d_cnt counts requested blocks (buffer parity)
-    int64_t d_slot = wq;
-    int d_kb = 0;
-    unsigned d_cnt = 0;
-    const unsigned char* d_xb = nullptr;
-    const unsigned char* d_wb = nullptr;
-    auto dma_tile = [&]() {  // operand base pointers of tile d_slot
-        const int64_t mblk = (d_slot / g.nb_n) * 8 + xcd;
-        const int n0 = (int)(d_slot % g.nb_n) * G::BN;
-        d_xb = reinterpret_cast<const unsigned char*>(g.X + mblk * G::BM * g.x_ld);
-        d_wb = reinterpret_cast<const unsigned char*>(g.W + (int64_t)n0 * g.Kpad);
+    // DMA cursors (records, weights): tile and k-block of the next block to request, the buffer it goes to, its source
+    struct Cursor { int64_t slot; int kb; int buf; const unsigned char* base; };
+    Cursor cx{wq, 0, 0, nullptr}, cw{wq, 0, 0, nullptr};
+    auto x_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.X + ((slot / g.nb_n) * 8 + xcd) * G::BM * g.x_ld); };
+    auto w_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.W + (int64_t)((int)(slot % g.nb_n) * G::BN) * g.Kpad); };
+    auto dma = [&](const unsigned char* gp, unsigned voff, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(gp), "s"(dst)
+                     : "memory");
     };
-    auto dma_ops = [&](int j0, int j1) {  // pieces [j0, j1) of this wave's 8 of block (d_slot, d_kb)
-        if (d_slot >= slots) return;
-        const int buf = d_cnt & 1;
-#pragma unroll
-        for (int j = j0; j < j1; ++j) {
-            const int o = wv * G::OPW + j, operand = o >= G::XCH, chunk = operand ? o - G::XCH : o;
-            const unsigned char* gp = (operand ? d_wb + (int64_t)chunk * 8 * g.Kpad * 2 : d_xb + (int64_t)chunk * 8 * g.x_ld * 2) + (int64_t)d_kb * BK * 2;
-            const unsigned voff = operand ? voff_w[chunk & 1] : voff_x[chunk & 1];
-            const unsigned dst = (unsigned)(buf * kBufBytes + operand * kTileX + chunk * 1024);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(voff), "s"(gp), "s"(dst)
-                         : "memory");
+    auto x_op = [&](int j) {  // piece j of this wave's XPW of the record block at the cursor
+        if (cx.slot >= slots) return;
+        const int chunk = wv * G::XPW + j;
+        dma(cx.base + (int64_t)chunk * 8 * g.x_ld * 2 + (int64_t)cx.kb * BK * 2, voff_x[chunk & 1], (unsigned)(cx.buf * kTileX + chunk * 1024));
+    };
+    auto w_op = [&](int j) {
+        if (cw.slot >= slots) return;
+        const int chunk = wv * G::WPW + j;
+        dma(cw.base + (int64_t)chunk * 8 * g.Kpad * 2 + (int64_t)cw.kb * BK * 2, voff_w[chunk & 1], (unsigned)(kWBase + cw.buf * kTileW + chunk * 1024));
+    };
+    auto x_advance = [&]() {
+        if (cx.slot >= slots) return;
+        cx.buf = cx.buf == 2 ? 0 : cx.buf + 1;
+        if (++cx.kb == nkb) {
+            cx.kb = 0;
+            cx.slot += wstride;
+            if (cx.slot < slots) cx.base = x_base(cx.slot);
         }
     };
-    auto dma_advance = [&]() {
-        if (d_slot >= slots) return;
-        ++d_cnt;
-        if (++d_kb == nkb) {
-            d_kb = 0;
-            d_slot += wstride;
-            if (d_slot < slots) dma_tile();
+    auto w_advance = [&]() {
+        if (cw.slot >= slots) return;
+        cw.buf ^= 1;
+        if (++cw.kb == nkb) {
+            cw.kb = 0;
+            cw.slot += wstride;
+            if (cw.slot < slots) cw.base = w_base(cw.slot);
         }
     };
     const unsigned char* lds = reinterpret_cast<const unsigned char*>(gb_smem);
     struct Frags { bf16x8 a[MW], b[NT]; };
-    auto read_frags = [&](Frags& f, int buf, int ks) {
+    auto read_frags = [&](Frags& f, int xb, int wb, int ks) {
 #pragma unroll
         for (int q = 0; q < MW; ++q) {
             const int ra = (wr * MW + q) * 32 + li, kp = ks * 2 + hh;
-            f.a[q] = *reinterpret_cast<const bf16x8*>(lds + buf * kBufBytes + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
+            f.a[q] = *reinterpret_cast<const bf16x8*>(lds + xb * kTileX + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int rb = wc * WN + q * 32 + li, kp = ks * 2 + hh;
-            f.b[q] = *reinterpret_cast<const bf16x8*>(lds + buf * kBufBytes + kTileX + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
+            f.b[q] = *reinterpret_cast<const bf16x8*>(lds + kWBase + wb * kTileW + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
         }
     };
 
@@ -169,24 +174,33 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
 
     // Schedule of one k-block (four 16-wide k-steps, fragment sets F0/F1 alternating, each read one k-step ahead):
     // the barrier sits BEFORE the last k-step's MFMAs, so the fragment reads that follow it (first k-step of the next
-    // block) and the DMA issue (block after next, into the buffer just released) are covered by 16 MFMAs instead of
-    // stalling the matrix pipe once per k-block.
+    // block) and the DMA issue (into the buffers just released) are covered by 16 MFMAs instead of stalling the matrix
+    // pipe once per k-block.  After the barrier of block c a wave requests its pieces of weight block c + 2, THEN of
+    // record block c + 3: loads return in order, so at the next block's wait `vmcnt(XPW)` — everything but those last
+    // record pieces — means record block c + 2 (requested a block earlier) and weight block c + 2 have landed.
     Frags F0, F1;
-    dma_tile();
-    dma_ops(0, G::OPW);
-    dma_advance();
+    cx.base = x_base(wq);
+    cw.base = w_base(wq);
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+        for (int j = 0; j < G::XPW; ++j) x_op(j);
+        x_advance();
+        if (b < 2) {
+#pragma unroll
+            for (int j = 0; j < G::WPW; ++j) w_op(j);
+            w_advance();
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    dma_ops(0, G::OPW);
-    dma_advance();
-    unsigned c_cnt = 0;  // consumed blocks (buffer parity)
+    int xi = 0, wi = 0;   // buffers of the block being consumed
+    bool x_tail = false;  // the previous block's tail requested record pieces after its weight pieces
 #ifdef DIAG_STAMPS
-    unsigned long long st_k = 0, st_e = 0, st_w0 = 0, st_wn = 0, st_n = 0, st_a, st_b;
+    unsigned long long st_k = 0, st_e = 0, st_w0 = 0, st_wn = 0, st_n = 0, st_s = 0, st_i = 0, st_a, st_b;
 #define STAMP(x) x = wall_clock64()
 #else
 #define STAMP(x)
 #endif
-    unsigned char* stage = reinterpret_cast<unsigned char*>(gb_smem) + 2 * kBufBytes + wid * kStageBytes;  // bf16 layers only
     for (int64_t slot = wq; slot < slots; slot += wstride) {
         const int64_t m0 = ((slot / g.nb_n) * 8 + xcd) * G::BM;
         const int n0 = (int)(slot % g.nb_n) * G::BN;
@@ -215,32 +229,51 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                     }
             }
         }
-        STAMP(st_a);
-        read_frags(F0, c_cnt & 1, 0);
-        for (int kb = 0; kb < nkb; ++kb, ++c_cnt) {
-            const int buf = c_cnt & 1;
-            read_frags(F1, buf, 1);
+#ifdef DIAG_STAMPS
+        { const unsigned long long t0 = st_a; STAMP(st_a); if (st_n) st_i += st_a - t0; }
+#endif
+        read_frags(F0, xi, wi, 0);
+        int w_stage = 0;
+        for (int kb = 0; kb < nkb; ++kb) {
+            read_frags(F1, xi, wi, 1);
             mfma_all(F0);
-            read_frags(F0, buf, 2);
+            read_frags(F0, xi, wi, 2);
             mfma_all(F1);
-            read_frags(F1, buf, 3);
+            read_frags(F1, xi, wi, 3);
             mfma_all(F0);
             STAMP(st_b);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // next block landed (this wave's share); F1 is in registers
-            __syncthreads();                                            // ... everyone's share, and buffer `buf` has no readers left
+            // next block landed (this wave's share); F1 is in registers.  The first wait of a tile is a full one: the
+            // previous tile's stores are outstanding too, and stores and loads do not return in order with each other.
+            if (kb != 0 && x_tail) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::XPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();  // ... everyone's share, and this block's buffers have no readers left
 #ifdef DIAG_STAMPS
             { const unsigned long long now = wall_clock64(); if (kb == 0) st_w0 += now - st_b; else st_wn += now - st_b; }
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            if (kb + 1 < nkb) read_frags(F0, buf ^ 1, 0);
+            const int xn = xi == 2 ? 0 : xi + 1;
+            if (kb + 1 < nkb) read_frags(F0, xn, wi ^ 1, 0);
+            // bf16 layers: the WEIGHT buffer just released is the tile's output staging area, so the last block's weight
+            // request (the short-latency one: L2) waits until this wave has staged its rows — a wave's pieces ARE its
+            // 4 KB of staging.  The record request goes out on time.
+            const bool hold_w = !OF32 && kb + 1 == nkb;
 #pragma unroll
             for (int mt = 0; mt < MW; ++mt) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_row(F1, mt);
                 __builtin_amdgcn_sched_barrier(0);
-                dma_ops(mt * G::OPW / MW, (mt + 1) * G::OPW / MW);  // block after next (possibly of the next tile) into the buffer just released
+#pragma unroll
+                for (int j = mt * G::OPW / MW; j < (mt + 1) * G::OPW / MW; ++j) {
+                    if (j >= G::WPW) x_op(j - G::WPW);
+                    else if (!hold_w) w_op(j);
+                }
             }
-            dma_advance();
+            if (!hold_w) w_advance();
+            x_tail = cx.slot < slots;
+            x_advance();
+            w_stage = wi;
+            xi = xn;
+            wi ^= 1;
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -255,15 +288,22 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         // the lanes' ds_write_b64 (32 rows, same gi) and the ds_read_b128 of the copy-out both touch every bank once
         // (a padded row stride of 144 B made the writes 4-way conflicted, a quarter of the kernel's time).  LDS
         // operations of one wave execute in order, so the piece needs no barrier.
+        unsigned char* stage = reinterpret_cast<unsigned char*>(gb_smem) + kWBase + w_stage * kTileW + wid * kStageBytes;  // bf16 layers only
+        // opaque copy of the lane id: everything the epilogue derives from it (staging slots, output addresses) is
+        // recomputed per tile instead of being hoisted out of the tile loop and kept alive — at 255 registers that
+        // spilled an address pair whose reload put a vmcnt(0) in front of every epilogue
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 31, hh_e = lane_e >> 5;
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
-            const int64_t row = m0 + (wr * MW + mt) * 32 + li;
+            const int64_t row = m0 + (wr * MW + mt) * 32 + li_e;
             float4 eq[NT * 4];  // time-embedding row of the record (first layer only): all eight loads in flight together
             if (g.emb) {
                 const int tr = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
 #pragma unroll
                 for (int i = 0; i < NT * 4; ++i) {
-                    const int n = n0 + wc * WN + (i >> 2) * 32 + 8 * (i & 3) + 4 * hh;
+                    const int n = n0 + wc * WN + (i >> 2) * 32 + 8 * (i & 3) + 4 * hh_e;
                     eq[i] = n < g.emb_ld ? *reinterpret_cast<const float4*>(g.emb + (int64_t)tr * g.emb_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -271,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int nl = nt * 32 + 8 * q + 4 * hh;  // feature inside the wave's 64
+                    const int nl = nt * 32 + 8 * q + 4 * hh_e;  // feature inside the wave's 64
                     const int n = n0 + wc * WN + nl;
                     float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
                     if (g.emb) {
@@ -291,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                         }
                     } else {
                         __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        *reinterpret_cast<uint2*>(stage + li * (WN * 2) + (((nl >> 2) ^ (li & 15)) * 8)) = *reinterpret_cast<const uint2*>(e);
+                        *reinterpret_cast<uint2*>(stage + li_e * (WN * 2) + (((nl >> 2) ^ (li_e & 15)) * 8)) = *reinterpret_cast<const uint2*>(e);
                     }
                 }
             }
@@ -299,12 +339,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                 uint16_t* yb = reinterpret_cast<uint16_t*>(g.Y);
 #pragma unroll
                 for (int i = 0; i < WN / 16; ++i) {
-                    const int pce = lane + 64 * i, r = pce / (WN / 8), c8 = (pce % (WN / 8)) * 8;
+                    const int pce = lane_e + 64 * i, r = pce / (WN / 8), c8 = (pce % (WN / 8)) * 8;
                     uint4 val = *reinterpret_cast<const uint4*>(stage + r * (WN * 2) + (((c8 >> 3) ^ ((r & 15) >> 1)) * 16));
                     if (r & 1) val = make_uint4(val.z, val.w, val.x, val.y);  // odd key: the pair's two granules are swapped
                     *reinterpret_cast<uint4*>(yb + (m0 + (wr * MW + mt) * 32 + r) * g.y_rs + n0 + wc * WN + c8) = val;
                 }
             }
+        }
+#ifdef DIAG_STAMPS
+        { const unsigned long long now = wall_clock64(); st_s += now - st_b; }
+#endif
+        if (!OF32) {  // the held-back weight request, into the buffer the staging just left
+#pragma unroll
+            for (int j = 0; j < G::WPW; ++j) w_op(j);
+            w_advance();
         }
 #ifdef DIAG_STAMPS
         STAMP(st_a); st_e += st_a - st_b;
@@ -315,6 +363,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     if (tid == 0 && g.stamps) {
         atomicAdd(g.stamps + 0, st_k); atomicAdd(g.stamps + 1, st_e); atomicAdd(g.stamps + 2, st_w0); atomicAdd(g.stamps + 3, st_wn);
         atomicAdd(g.stamps + 4, st_n); atomicAdd(g.stamps + 5, st_n * (unsigned long long)nkb);
+        atomicAdd(g.stamps + 6, st_s); atomicAdd(g.stamps + 7, st_i);
     }
 #endif
 }
@@ -377,7 +426,7 @@ int n_cus_layered(int device) {
 template <bool OF32, int WR, int MW>
 int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     typedef Geo<WR, MW> G;
-    constexpr size_t lds = lds_bytes<OF32, WR, MW>();
+    constexpr size_t lds = lds_bytes<WR, MW>();
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32, WR, MW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -404,8 +453,8 @@ int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     unsigned long long h[8];
     MTK_HIP(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
     const double n = h[4] ? (double)h[4] : 1.0;
-    fprintf(stderr, "[layered stamps] K=%d N=%d tiles=%llu per tile (10 ns ticks): k-loop %.0f epilogue %.0f first-wait %.1f other-waits(avg each) %.1f\n", g.Kpad,
-            g.nb_n * G::BN, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] > h[4] ? (double)h[3] / (double)(h[5] - h[4]) : 0.0);
+    fprintf(stderr, "[layered stamps] K=%d N=%d tiles=%llu per tile (10 ns ticks): k-loop %.0f epilogue %.0f first-wait %.1f other-waits(avg each) %.1f | epilogue to stores issued %.0f, accumulator init %.0f\n", g.Kpad,
+            g.nb_n * G::BN, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] > h[4] ? (double)h[3] / (double)(h[5] - h[4]) : 0.0, h[6] / n, h[7] / n);
 #endif
     return MTK_OK;
 }
