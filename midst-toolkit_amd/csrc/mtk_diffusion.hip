@@ -550,7 +550,10 @@ struct PhiloxW {
 // columns, or the kKCache logits of the NEXT categorical block while the current one is being reduced) so that
 // several memory round trips are in flight per wave instead of one.
 constexpr int kGroup = 8;
-constexpr int kKCache = 16;
+constexpr int kKCache = 16;       // widest categorical block held in registers
+constexpr int kKCacheSmall = 12;  // ... when no block of the table is wider than this: 8-16 fewer registers per lane, which
+                                  // is what lets k_loss_rows_fast run five waves per SIMD instead of four (it is bound by
+                                  // the bytes it keeps in flight: 3.67 -> 4.13 TB/s at shape M)
 
 // The reference's record matrix is row-major: a lane reading "its" row makes every load touch 64 different cache
 // lines (120-byte stride), and 30 such loads per record wave cost more L1 tag cycles than the whole kernel's
@@ -579,30 +582,31 @@ __device__ __forceinline__ void stage_done() {  // before the slab is overwritte
     __builtin_amdgcn_wave_barrier();
 }
 
-// raw logits of one categorical block, held in registers when the block has at most kKCache columns
+// raw logits of one categorical block, held in registers when the block has at most KC columns
+template <int KC>
 struct BlockRaw {
-    float v[kKCache];
+    float v[KC];
     __device__ __forceinline__ void load(const float* mc, int64_t cs, int Kk) {
 #pragma unroll
-        for (int i = 0; i < kKCache; ++i) v[i] = (i < Kk) ? mc[i * cs] : -INFINITY;
+        for (int i = 0; i < KC; ++i) v[i] = (i < Kk) ? mc[i * cs] : -INFINITY;
     }
 };
 // e_i = exp(logit_i - max) and their sum, from registers (CACHED) or recomputed from memory in every pass
-template <bool CACHED>
+template <bool CACHED, int KC>
 struct BlockExp {
-    float e[CACHED ? kKCache : 1];
+    float e[CACHED ? KC : 1];
     const float* mc;
     int64_t cs;
     int Kk;
     float mx, sum;
-    __device__ __forceinline__ BlockExp(const BlockRaw& raw, const float* mc_, int64_t cs_, int Kk_) : mc(mc_), cs(cs_), Kk(Kk_) {
+    __device__ __forceinline__ BlockExp(const BlockRaw<KC>& raw, const float* mc_, int64_t cs_, int Kk_) : mc(mc_), cs(cs_), Kk(Kk_) {
         mx = -INFINITY;
         sum = 0.0f;
         if (CACHED) {
 #pragma unroll
-            for (int i = 0; i < kKCache; ++i) mx = fmaxf(mx, raw.v[i]);
+            for (int i = 0; i < KC; ++i) mx = fmaxf(mx, raw.v[i]);
 #pragma unroll
-            for (int i = 0; i < kKCache; ++i) {
+            for (int i = 0; i < KC; ++i) {
                 e[i] = __expf(raw.v[i] - mx);  // 0 for the padding columns
                 sum += e[i];
             }
@@ -615,7 +619,7 @@ struct BlockExp {
     __device__ __forceinline__ void each(F&& f) const {
         if (CACHED) {
 #pragma unroll
-            for (int i = 0; i < kKCache; ++i)
+            for (int i = 0; i < KC; ++i)
                 if (i < Kk) f(i, e[i]);
         } else {
             for (int i = 0; i < Kk; ++i) f(i, __expf(mc[i * cs] - mx));
@@ -724,8 +728,8 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
 
 struct TruePost { float lt_c0, lt_ct, w_c0, w_ct, w_cc, w_sum, self; };
 
-template <bool LDS_ROWS, bool STAGE>
-__global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
+template <bool LDS_ROWS, bool STAGE, int KC>
+__device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
     const SchedRow srT = s.rows[T - 1];
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
         const float* mo = a.mo + row * a.mo_rs;
         const bool multi = a.loss_multi && C > 0;
         // the first categorical block's inputs go out before the Gaussian part is consumed
-        BlockRaw raw;
+        BlockRaw<KC> raw;
         int c0 = 0, ct = 0;
         if (multi) {
             raw.load(mo + (int64_t)Nn * a.mo_cs, a.mo_cs, s.off[1]);
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
             const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
             // next block's inputs
-            BlockRaw nxt;
+            BlockRaw<KC> nxt;
             int c0n = 0, ctn = 0;
             if (k + 1 < C) {
                 nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
             // model posterior in probability space: P_i = (A e_i + Bc) Q_i, log p_i = log P_i - log sum P
             float total = 0.0f, sum_log_cc = 0.0f, lp_c0 = 0.0f, lp_ct = 0.0f;
             auto model = [&](auto tag) {
-                const BlockExp<decltype(tag)::value> be(raw, mc, a.mo_cs, Kk);
+                const BlockExp<decltype(tag)::value, KC> be(raw, mc, a.mo_cs, Kk);
                 const float A = acp1 / be.sum;
                 be.each([&](int i, float e) {
                     const float P = (A * e + Bc) * ((i == ct) ? Qh : Qc);
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
                     else sum_log_cc += lp;
                 });
             };
-            if (Kk <= kKCache) model(CachedTag{}); else model(StreamTag{});
+            if (Kk <= KC) model(CachedTag{}); else model(StreamTag{});
             const float lse_m = flog(total);
             float cross = w_c0 * lp_c0 + w_cc * sum_log_cc;              // sum_i w_i log P_i
             if (!eq) cross += w_ct * lp_ct;
@@ -868,6 +872,15 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) {
     }
 }
 
+template <bool LDS_ROWS, bool STAGE>
+__global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) { loss_rows_fast_body<LDS_ROWS, STAGE, kKCache>(a); }
+// no block wider than kKCacheSmall: 96 registers, five waves per SIMD
+template <bool LDS_ROWS, bool STAGE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_loss_rows_fast_small(LossArgs a) {
+    loss_rows_fast_body<LDS_ROWS, STAGE, kKCacheSmall>(a);
+}
+
+template <int KC>
 __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
     const Staged s = stage_tables<false>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S, t = a.t;
@@ -879,7 +892,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
         PhiloxNF pn(a.seed, a.row0 + row, stream_n);
         PhiloxW pu(a.seed, a.row0 + row, stream_u);
         // the first categorical block's inputs go out before the numeric part is consumed
-        BlockRaw raw;
+        BlockRaw<KC> raw;
         int cz = 0;
         if (C > 0 && !a.u) {
             raw.load(mo + (int64_t)Nn * a.mo_cs, a.mo_cs, s.off[1]);
@@ -954,7 +967,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
             const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
-            BlockRaw nxt;
+            BlockRaw<KC> nxt;
             int czn = 0;
             if (k + 1 < C) {
                 nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
@@ -967,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
             const float u1 = pu.uniform(k);
             int arg = Kk - 1;
             auto draw = [&](auto tag) {
-                const BlockExp<decltype(tag)::value> be(raw, mc, a.mo_cs, Kk);
+                const BlockExp<decltype(tag)::value, KC> be(raw, mc, a.mo_cs, Kk);
                 const float A = acp1 / be.sum;
                 float total = 0.0f;
                 be.each([&](int i, float e) { total += (A * e + Bc) * ((i == cz) ? Qh : Qc); });
@@ -979,7 +992,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                     if (!found && cum > target) { arg = i; found = true; }
                 });
             };
-            if (Kk <= kKCache) draw(CachedTag{}); else draw(StreamTag{});
+            if (Kk <= KC) draw(CachedTag{}); else draw(StreamTag{});
             a.z_idx[(int64_t)k * a.B + row] = arg;
             if (xo) {
                 float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
@@ -1134,6 +1147,11 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
     }
 }
 
+int max_levels(const mtk_ctx* c) {  // widest categorical block of the table
+    int m = 0;
+    for (int32_t k : c->K) m = k > m ? k : m;
+    return m;
+}
 int grid_for(int64_t B) {
     int64_t g = (B + kBlock - 1) / kBlock;
     if (g > 2048) g = 2048;  // 256 CUs x 8 resident workgroups; grid-stride covers the rest
@@ -1200,13 +1218,17 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     LossArgs a{ctx->dev(), B, model_out, mo_rs, mo_cs, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, seed, row0};
     const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
     const bool stage = ctx->fast_math && loss_multi && ctx->C > 0 && x0_ld <= kStageLd && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && !getenv("MTK_NO_STAGE");
+    const bool small = max_levels(ctx) <= kKCacheSmall;
     if (stage) {  // as in mtk_q_sample
-        hipLaunchKernelGGL((k_loss_rows_fast<false, true>), dim3(grid_for(B)), dim3(kBlock),
+        auto ks = small ? k_loss_rows_fast_small<false, true> : k_loss_rows_fast<false, true>;
+        hipLaunchKernelGGL(ks, dim3(grid_for(B)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
         return MTK_OK;
     }
-    auto k = ctx->fast_math ? (lds ? k_loss_rows_fast<true, false> : k_loss_rows_fast<false, false>) : (lds ? k_loss_rows<true> : k_loss_rows<false>);
+    auto kf = small ? (lds ? k_loss_rows_fast_small<true, false> : k_loss_rows_fast_small<false, false>)
+                    : (lds ? k_loss_rows_fast<true, false> : k_loss_rows_fast<false, false>);
+    auto k = ctx->fast_math ? kf : (lds ? k_loss_rows<true> : k_loss_rows<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -1239,7 +1261,8 @@ extern "C" int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int firs
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
     a.z = z; a.z_idx = z_idx; a.noise = noise; a.noise_f64 = noise_is_f64; a.u = u;
     a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
-    hipLaunchKernelGGL(ctx->fast_math ? k_p_sample_step_fast : k_p_sample_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false),
+    auto kstep = !ctx->fast_math ? k_p_sample_step : (max_levels(ctx) <= kKCacheSmall ? k_p_sample_step_fast<kKCacheSmall> : k_p_sample_step_fast<kKCache>);
+    hipLaunchKernelGGL(kstep, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false),
                        (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;

@@ -590,6 +590,70 @@ def test_fast_math_against_oracle(tag, monkeypatch):
         check_categorical(zid.t(), want_zi, logp, uu, c["K"])
 
 
+def test_fast_math_wide_blocks(monkeypatch):
+    """Blocks wider than the small register cache (12): 14 and 16 levels take the 16-column cached kernels, 20 levels the
+    streaming pass.  Same checks as above with a random denoiser output, plus the in-kernel-noise draws stay in range."""
+    import midst_toolkit_amd as mtk
+
+    K, Nn, T, B = [14, 3, 16, 20, 5], 4, 1000, 4096
+    c = {"K": K, "Nn": Nn, "S": sum(K), "T": T}
+    C, S, D = len(K), sum(K), Nn + sum(K)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+    d = mtk.GaussianMultinomialDiffusion(np.array(K), Nn, net, num_timesteps=T, device=dev()).to(dev())
+    d.math = "fast"
+    eng = d.engine()
+    s = orc.make_schedule(T, "cosine")
+    x0, t, eps, u = _big_mixed_batch(c, B, seed=21)
+    want_xt, want_idx = orc.q_sample_fused(s, K, Nn, x0, t, eps, u)
+    x_in = torch.empty((D, B), device=dev())
+    idx = torch.empty((C, B), dtype=torch.int32, device=dev())
+    eng.q_sample(x0.to(dev()), t.to(dev()), eps.to(dev()), u.to(dev()), x_in, (1, B), idx)
+    logits = orc.q_pred(s, orc.log_onehot(x0[:, Nn:].long(), K), t, orc.log_k_expanded(K))
+    monkeypatch.setattr(sys.modules[__name__], "TIE_MARGIN", 2e-4)
+    check_categorical(idx.t(), want_idx, logits, u, K)
+    g = torch.Generator().manual_seed(4)
+    out = torch.randn((B, D), generator=g) * 2
+    wm, wg = orc.loss_rows(s, K, Nn, out, x0, want_idx, eps, t)
+    lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+    eng.loss_rows(colmajor(out), (1, B), x0.to(dev()), want_idx.t().contiguous().int().to(dev()), eps.to(dev()), t.to(dev()), lm, lg)
+    close(lg, wg, rtol=1e-5)
+    assert abs(float(lm.mean().cpu()) - float(wm.mean())) <= RTOL * abs(float(wm.mean()))
+    floor = orc.multinomial_loss_floor(s, K, Nn, out, x0, want_idx, t)
+    err = (lm.cpu().double() - wm.double()).abs()
+    bar = RTOL * wm.abs().double() + 3 * floor + 1e-5
+    assert bool((err <= bar).all()), float((err / bar).max())
+    for tt_ in (T // 2, 0):
+        g = torch.Generator().manual_seed(tt_ + 6)
+        mo = torch.randn((B, D), generator=g) * 2
+        z = torch.randn((B, Nn), generator=g, dtype=torch.float64)
+        zi = torch.stack([torch.randint(0, int(k), (B,), generator=g) for k in K], 1)
+        n = torch.randn((B, Nn), generator=g, dtype=torch.float64)
+        uu = torch.rand((B, S), generator=g)
+        tv = torch.full((B,), tt_, dtype=torch.long)
+        logp = orc.q_posterior(s, orc.block_log_softmax(mo[:, Nn:], K), orc.log_onehot(zi, K), tv, K)
+        want_zi = orc.gumbel_argmax(logp, uu, K)
+        zd = z.t().contiguous().to(dev())
+        zid = zi.t().contiguous().int().to(dev())
+        eng.p_sample_step(B, tt_, False, colmajor(mo), (1, B), zd, zid, n.to(dev()), uu.to(dev()), None, (1, B))
+        close(zd.t(), orc.gaussian_p_step(s, mo[:, :Nn], z, tt_, n), rtol=1e-12, atol=1e-12)
+        check_categorical(zid.t(), want_zi, logp, uu, K)
+        # in-kernel noise (inverse-CDF draws from the register-cached / streamed blocks): the empirical distribution of
+        # the widest cached block (16 levels) and the streamed one (20) follows the oracle's posterior
+        zid2 = zi.t().contiguous().int().to(dev())
+        zd2 = z.t().contiguous().to(dev())
+        eng.p_sample_step(B, tt_, False, colmajor(mo), (1, B), zd2, zid2, None, None, None, (1, B), seed=77)
+        got = zid2.t().cpu().long()
+        off = orc.offsets_of(K)
+        for k in (2, 3):
+            assert int(got[:, k].min()) >= 0 and int(got[:, k].max()) < K[k]
+            p = torch.exp(logp[:, off[k]:off[k + 1]].double())
+            p = p / p.sum(1, keepdim=True)
+            expect = p.sum(0)                                   # expected count per level
+            count = torch.bincount(got[:, k], minlength=K[k]).double()
+            var = (p * (1 - p)).sum(0)
+            assert bool(((count - expect).abs() <= 5 * var.sqrt() + 1).all()), (k, count.tolist(), expect.tolist())
+
+
 def test_fast_math_staged_rows_equal_direct_rows():
     """The fast kernels copy a wave's 64 row-major records into LDS when x0 is 16-byte aligned and narrow, and read
     them through strides otherwise: same arithmetic, so outputs are identical — full waves and a ragged last wave."""
