@@ -12,17 +12,16 @@
 // reads ride under the other's MFMAs; with 4 waves of 4 x 4 tiles the same loop ran at 690 instead of 830 TFLOP/s).
 // The tile size is set by the memory system: per 16-wide k-step a workgroup pulls 16 KB from L2 for 64 MFMAs
 // (32 B/clk/CU, half of what a 128 x 128 tile needs).  Both operands are row-major [rows][K] bf16, so a lane's 8
-// k-values are one 16-byte read.  L2 -> LDS by LDS-DMA into a double buffer: the next k-block lands during the
-// MFMAs, one barrier per k-block, no staging registers.  The kernel is persistent (one workgroup per CU walks its
-// tiles; the k-blocks of all of them form one DMA stream) and its epilogue issues no vector loads (bias through the
-// scalar cache into the accumulator init).
+// k-values are one 16-byte read.  L2 -> LDS by LDS-DMA, no staging registers; THREE record buffers and two weight
+// buffers (160 KB): records are the long-latency operand.  The kernel is persistent (one workgroup per CU walks its
+// tiles; the k-blocks of all of them form one DMA stream), its epilogue uses neither vector loads (bias through the
+// scalar cache into the accumulator init) nor LDS (v_permlane32_swap pairs the two half-pieces of a record's 16 bytes).
 //
-// Measured (2^20 records, 4x1024, MI355X, same box): 8.0 ms = 890 TFLOP/s (round start 8.8 ms).  In-kernel stamps
-// (-DDIAG_STAMPS, tools/build_variant.sh), per 256 x 256 x 1024 tile: k-loop 30.5 us, epilogue 3.4 us (was 28.3 + 5.8
-// with sixteen load -> vmcnt(0) round trips per 32 rows in the epilogue: removing them moved the stores' drain into the
-// next k-loop instead of shortening the tile).  In the k-loop a wave waits 0.6 us per k-block (1.9 us) at the
-// vmcnt(0) + barrier for the next block's DMA: the loop is bound by DMA latency (~2 us, records come from HBM or the
-// Infinity Cache) with one 64 KB block in flight — LDS capacity, not MFMA rate (0.85 us per block), sets the pace.
+// Measured (2^20 records, 4x1024, MI355X, same box): 7.6 ms = 945 TFLOP/s (round start 8.75 ms).  In-kernel stamps
+// (-DDIAG_STAMPS, tools/build_variant.sh), per 256 x 256 x 1024 tile: k-loop 24.5 us, epilogue 2.5 us, accumulator
+// init 0.35 us, first wait of a tile (drains the previous tile's stores) 1.4 us, other waits 0.45 us per k-block
+// (1.5 us) against 0.85 us of MFMA time.  History of the epilogue: 5.8 us with sixteen load -> vmcnt(0) round trips
+// per 32 rows; 3.2 us staged through LDS with a vmcnt(0) the compiler had put at the join of the `if (emb)` branch.
 #include <math.h>
 #include <stdlib.h>
 
@@ -37,7 +36,6 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int BT = 256, BK = 64;
 constexpr int kRowPad = 256;  // activation matrices are padded to the record tile
 constexpr int NT = 2, WN = NT * 32;  // a wave's tile: 128 records (4 MFMA tiles) x 64 features (2)
-constexpr int kStageBytes = 32 * WN * 2;  // per wave: 32 rows x 64 bf16 of output staging, 4 KB
 // Wave grid WR x (8 / WR), MW 32-record MFMA tiles per wave.  <2, 4> is the 256 x 256 tile of the hidden layers (record
 // tile 32 KB + weight tile 32 KB per k-block).  <4, 2> is a 256 x 128 tile for a narrow head (N <= 128: 32 KB + 16 KB):
 // no MFMAs spent on 128 padding columns, and still one tile per 256 records, so a 65,536-row pass fills all 256 CUs.
@@ -45,8 +43,7 @@ template <int WR, int MW> struct Geo {
     static constexpr int WC = 8 / WR, BM = WR * MW * 32, BN = WC * WN;
     static constexpr int kTileX = BM * BK * 2, kTileW = BN * BK * 2, kBuf = kTileX + kTileW;
     static constexpr int XPW = BM / 64, WPW = BN / 64, OPW = XPW + WPW;  // 8-row, 1 KiB DMA pieces per wave and k-block: records, weights
-    static_assert(WR != 2 || kTileW == 8 * kStageBytes, "the output staging of a bf16 tile borrows one weight buffer");
-};
+    };
 // THREE record buffers and two weight buffers (96 + 64 KB = 160 KB for the hidden layers): records are the long-latency
 // operand (HBM / Infinity Cache, ~2 us), weights hit the L2, so the record stream runs one k-block further ahead.
 template <int WR, int MW> constexpr size_t lds_bytes() { return 3 * Geo<WR, MW>::kTileX + 2 * Geo<WR, MW>::kTileW; }
@@ -73,7 +70,10 @@ extern __shared__ __attribute__((aligned(16))) uint16_t gb_smem[];
 // through the LDS buffers — the weight cursor runs two blocks ahead of the MFMAs, the record cursor three, across tile
 // boundaries.  A tile's epilogue (ReLU, bf16 rounding, staging, stores) therefore runs with the next tile's first blocks
 // already in flight, its stores drain under the next tile's MFMAs, and there is no per-tile launch / first-load latency.
-template <bool OF32, int WR, int MW>
+// EMB: the first layer's epilogue adds the record's time-embedding row (vector loads).  It is a template parameter, not
+// a run-time branch: the compiler put the loads' `s_waitcnt vmcnt(0)` at the join of the branch, where every layer
+// then waited, once per 32 rows, for its previous stores and the DMA in flight (~1 us each).
+template <bool OF32, int WR, int MW, bool EMB>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     typedef Geo<WR, MW> G;
     constexpr int kTileX = G::kTileX, kTileW = G::kTileW, kWBase = 3 * G::kTileX;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     int xi = 0, wi = 0;   // buffers of the block being consumed
     bool x_tail = false;  // the previous block's tail requested record pieces after its weight pieces
 #ifdef DIAG_STAMPS
-    unsigned long long st_k = 0, st_e = 0, st_w0 = 0, st_wn = 0, st_n = 0, st_s = 0, st_i = 0, st_a, st_b;
+    unsigned long long st_k = 0, st_e = 0, st_w0 = 0, st_wn = 0, st_n = 0, st_s = 0, st_i = 0, st_m0 = 0, st_m1 = 0, st_a, st_b;
 #define STAMP(x) x = wall_clock64()
 #else
 #define STAMP(x)
@@ -233,7 +233,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         { const unsigned long long t0 = st_a; STAMP(st_a); if (st_n) st_i += st_a - t0; }
 #endif
         read_frags(F0, xi, wi, 0);
-        int w_stage = 0;
         for (int kb = 0; kb < nkb; ++kb) {
             read_frags(F1, xi, wi, 1);
             mfma_all(F0);
@@ -253,10 +252,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
             __builtin_amdgcn_sched_barrier(0);
             const int xn = xi == 2 ? 0 : xi + 1;
             if (kb + 1 < nkb) read_frags(F0, xn, wi ^ 1, 0);
-            // bf16 layers: the WEIGHT buffer just released is the tile's output staging area, so the last block's weight
-            // request (the short-latency one: L2) waits until this wave has staged its rows — a wave's pieces ARE its
-            // 4 KB of staging.  The record request goes out on time.
-            const bool hold_w = !OF32 && kb + 1 == nkb;
 #pragma unroll
             for (int mt = 0; mt < MW; ++mt) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -264,14 +259,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = mt * G::OPW / MW; j < (mt + 1) * G::OPW / MW; ++j) {
-                    if (j >= G::WPW) x_op(j - G::WPW);
-                    else if (!hold_w) w_op(j);
+                    if (j < G::WPW) w_op(j);
+                    else x_op(j - G::WPW);
                 }
             }
-            if (!hold_w) w_advance();
+            w_advance();
             x_tail = cx.slot < slots;
             x_advance();
-            w_stage = wi;
             xi = xn;
             wi ^= 1;
             __builtin_amdgcn_sched_barrier(0);
@@ -288,7 +282,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         // the lanes' ds_write_b64 (32 rows, same gi) and the ds_read_b128 of the copy-out both touch every bank once
         // (a padded row stride of 144 B made the writes 4-way conflicted, a quarter of the kernel's time).  LDS
         // operations of one wave execute in order, so the piece needs no barrier.
-        unsigned char* stage = reinterpret_cast<unsigned char*>(gb_smem) + kWBase + w_stage * kTileW + wid * kStageBytes;  // bf16 layers only
         // opaque copy of the lane id: everything the epilogue derives from it (staging slots, output addresses) is
         // recomputed per tile instead of being hoisted out of the tile loop and kept alive — at 255 registers that
         // spilled an address pair whose reload put a vmcnt(0) in front of every epilogue
@@ -299,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         for (int mt = 0; mt < MW; ++mt) {
             const int64_t row = m0 + (wr * MW + mt) * 32 + li_e;
             float4 eq[NT * 4];  // time-embedding row of the record (first layer only): all eight loads in flight together
-            if (g.emb) {
+            if (EMB) {
                 const int tr = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
 #pragma unroll
                 for (int i = 0; i < NT * 4; ++i) {
@@ -309,12 +302,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                unsigned pk[4][2];  // [q]: the lane's 4 features of group q as two packed bf16 pairs
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int nl = nt * 32 + 8 * q + 4 * hh_e;  // feature inside the wave's 64
                     const int n = n0 + wc * WN + nl;
                     float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
-                    if (g.emb) {
+                    if (EMB) {
                         const float4 e4 = eq[nt * 4 + q];
                         v[0] += e4.x; v[1] += e4.y; v[2] += e4.z; v[3] += e4.w;
                     }
@@ -330,30 +324,33 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                                 if (n + j < g.N) yf[row * g.y_rs + (int64_t)(n + j) * g.y_cs] = v[j];
                         }
                     } else {
-                        __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        *reinterpret_cast<uint2*>(stage + li_e * (WN * 2) + (((nl >> 2) ^ (li_e & 15)) * 8)) = *reinterpret_cast<const uint2*>(e);
+                        const __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        pk[q][0] = reinterpret_cast<const unsigned*>(e)[0];
+                        pk[q][1] = reinterpret_cast<const unsigned*>(e)[1];
+                    }
+                }
+                if (!OF32) {
+                    // A lane holds features 8q + 4 (lane >> 5) + [0, 4) of its record: lanes l and l + 32 hold the two
+                    // halves of every 8-feature (16-byte) piece.  v_permlane32_swap trades the upper lanes' half of the
+                    // even group for the lower lanes' half of the odd group, so each lane ends up with one whole piece
+                    // (lower lanes: the odd group, upper lanes: the even one) and stores 16 bytes; the two lanes of a
+                    // record write 32 contiguous bytes, a row's 128 bytes leave in four instructions.  No LDS staging.
+                    uint16_t* yb = reinterpret_cast<uint16_t*>(g.Y) + row * g.y_rs + n0 + wc * WN + nt * 32;
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][0], pk[2 * p2][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][1], pk[2 * p2][1], false, false);
+                        *reinterpret_cast<uint4*>(yb + 8 * (2 * p2 + (hh_e ? 0 : 1))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                     }
                 }
             }
-            if (!OF32) {  // rows [wr * 128 + mt * 32, + 32) of the wave are staged: 256 pieces of 16 B, 4 per lane
-                uint16_t* yb = reinterpret_cast<uint16_t*>(g.Y);
-#pragma unroll
-                for (int i = 0; i < WN / 16; ++i) {
-                    const int pce = lane_e + 64 * i, r = pce / (WN / 8), c8 = (pce % (WN / 8)) * 8;
-                    uint4 val = *reinterpret_cast<const uint4*>(stage + r * (WN * 2) + (((c8 >> 3) ^ ((r & 15) >> 1)) * 16));
-                    if (r & 1) val = make_uint4(val.z, val.w, val.x, val.y);  // odd key: the pair's two granules are swapped
-                    *reinterpret_cast<uint4*>(yb + (m0 + (wr * MW + mt) * 32 + r) * g.y_rs + n0 + wc * WN + c8) = val;
-                }
-            }
+#ifdef DIAG_STAMPS
+            if (mt == 0) st_m1 += wall_clock64() - st_b;
+#endif
         }
 #ifdef DIAG_STAMPS
         { const unsigned long long now = wall_clock64(); st_s += now - st_b; }
 #endif
-        if (!OF32) {  // the held-back weight request, into the buffer the staging just left
-#pragma unroll
-            for (int j = 0; j < G::WPW; ++j) w_op(j);
-            w_advance();
-        }
 #ifdef DIAG_STAMPS
         STAMP(st_a); st_e += st_a - st_b;
 #endif
@@ -363,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     if (tid == 0 && g.stamps) {
         atomicAdd(g.stamps + 0, st_k); atomicAdd(g.stamps + 1, st_e); atomicAdd(g.stamps + 2, st_w0); atomicAdd(g.stamps + 3, st_wn);
         atomicAdd(g.stamps + 4, st_n); atomicAdd(g.stamps + 5, st_n * (unsigned long long)nkb);
-        atomicAdd(g.stamps + 6, st_s); atomicAdd(g.stamps + 7, st_i);
+        atomicAdd(g.stamps + 6, st_s); atomicAdd(g.stamps + 7, st_i); atomicAdd(g.stamps + 8, st_m0); atomicAdd(g.stamps + 9, st_m1);
     }
 #endif
 }
@@ -423,13 +420,13 @@ int n_cus_layered(int device) {
     return n;
 }
 
-template <bool OF32, int WR, int MW>
+template <bool OF32, int WR, int MW, bool EMB = false>
 int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     typedef Geo<WR, MW> G;
     constexpr size_t lds = lds_bytes<WR, MW>();
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32, WR, MW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32, WR, MW, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     if (Mpad % G::BM || Npad % G::BN) MTK_FAIL(MTK_ERR_STATE, "layered bf16 GEMM: %lld x %d is not a multiple of the %d x %d tile", (long long)Mpad, Npad, G::BM, G::BN);
@@ -442,19 +439,19 @@ int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     if (most < per_xcd) per_xcd = most;
 #ifdef DIAG_STAMPS
     static unsigned long long* d_st = nullptr;
-    if (!d_st) MTK_HIP(hipMalloc(&d_st, 64));
-    MTK_HIP(hipMemsetAsync(d_st, 0, 64, s));
+    if (!d_st) MTK_HIP(hipMalloc(&d_st, 128));
+    MTK_HIP(hipMemsetAsync(d_st, 0, 128, s));
     g.stamps = d_st;
 #endif
-    hipLaunchKernelGGL((k_gemm_bf16<OF32, WR, MW>), dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_gemm_bf16<OF32, WR, MW, EMB>), dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, g);
     MTK_HIP(hipGetLastError());
 #ifdef DIAG_STAMPS
     MTK_HIP(hipStreamSynchronize(s));
-    unsigned long long h[8];
-    MTK_HIP(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
+    unsigned long long h[16];
+    MTK_HIP(hipMemcpy(h, d_st, 128, hipMemcpyDeviceToHost));
     const double n = h[4] ? (double)h[4] : 1.0;
-    fprintf(stderr, "[layered stamps] K=%d N=%d tiles=%llu per tile (10 ns ticks): k-loop %.0f epilogue %.0f first-wait %.1f other-waits(avg each) %.1f | epilogue to stores issued %.0f, accumulator init %.0f\n", g.Kpad,
-            g.nb_n * G::BN, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] > h[4] ? (double)h[3] / (double)(h[5] - h[4]) : 0.0, h[6] / n, h[7] / n);
+    fprintf(stderr, "[layered stamps] K=%d N=%d tiles=%llu per tile (10 ns ticks): k-loop %.0f epilogue %.0f first-wait %.1f other-waits(avg each) %.1f | epilogue to stores issued %.0f (first 32 rows staged %.0f, their stores issued %.0f), accumulator init %.0f\n", g.Kpad,
+            g.nb_n * G::BN, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] > h[4] ? (double)h[3] / (double)(h[5] - h[4]) : 0.0, h[6] / n, h[8] / n, h[9] / n, h[7] / n);
 #endif
     return MTK_OK;
 }
@@ -538,7 +535,7 @@ int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs
         g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar;
         int ld = round_up(c->proj.out_pad, BT);
         g.Y = ws[cur ^ 1]; g.y_rs = ld;
-        if ((rc = launch<false, 2, 4>(g, c->device, Mpad, ld, s))) return rc;
+        if ((rc = launch<false, 2, 4, true>(g, c->device, Mpad, ld, s))) return rc;
         cur ^= 1;
         for (size_t i = 0; i < c->blocks.size(); ++i) {
             const MlpLayer& l = c->blocks[i];
