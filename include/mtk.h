@@ -61,7 +61,8 @@ enum mtk_table {
     MTK_TAB_MODEL_VAR64 = 11,   /* [posterior_variance[1], (1-alphas)[1:]] in fp64 (the "variance" of GMD:425, used by condition_mean GMD:615) */
     MTK_TAB_ACP = 12,           /* alphas_cumprod                 GMD:260 */
     MTK_TAB_ACP_PREV = 13,      /* alphas_cumprod_prev            GMD:261 (DDIM, GMD:1106-1107, 1240-1241) */
-    MTK_NTAB = 14
+    MTK_TAB_POST_LOGVAR_CLIPPED = 14, /* posterior_log_variance_clipped (fp32 values) GMD:224-225 (KL Gaussian loss, GMD:459) */
+    MTK_NTAB = 15
 };
 
 /* Denoiser arithmetic. */
@@ -195,6 +196,15 @@ int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z
 int mtk_quantile_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, const double* quantiles,
                          const double* references, int n_quantiles, int output_normal, double* out, int64_t out_ld,
                          mtk_stream stream);
+
+/* Replaces _gaussian_loss with GaussianLossType.KL (GMD:534-541 -> _vb_terms_bpd GMD:431-484; normal_kl DU:9-45,
+ * discretized_gaussian_log_likelihood DU:62-91) for the EPS parametrisation: per record, in bits per dimension, the
+ * decoder NLL where t == 0 and KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) elsewhere.  model_out / x_t: the numeric block
+ * of the denoiser output / input, element (row, j) at [row * rs + j * cs]; x0: [B, x0_ld] row-major (numeric columns
+ * first); t [B] int64; loss [B] fp64 (the reference's result is fp64: its model log-variance row is). */
+int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out, int64_t mo_rs, int64_t mo_cs, const float* x0,
+                      int64_t x0_ld, const float* x_t, int64_t xt_rs, int64_t xt_cs, const int64_t* t, double* loss,
+                      mtk_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training iteration.  Replaces ClavaDDPMTrainer._train_step /

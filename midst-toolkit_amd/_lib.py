@@ -16,11 +16,12 @@ LIB_PATH = os.environ.get("MTK_LIB_PATH") or os.path.join(_HERE, "libmtk_hip.so"
 
 MTK_OK, MTK_ERR_ARG, MTK_ERR_UNSUPPORTED, MTK_ERR_HIP, MTK_ERR_STATE = 0, -1, -2, -3, -4
 PREC_FP32, PREC_BF16 = 0, 1
-NTAB = 14
+NTAB = 15
 TABLE_ORDER = [
     "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_alpha", "log_1_min_alpha", "log_cumprod_alpha",
     "log_1_min_cumprod_alpha", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
     "posterior_mean_coef2", "model_log_variance", "model_variance", "alphas_cumprod", "alphas_cumprod_prev",
+    "posterior_log_variance_clipped",
 ]
 
 _lib = None
@@ -38,6 +39,7 @@ _SIGS = {
     "mtk_loss_rows": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),
     "mtk_tf_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _i32, _p, _i32, _p]),
     "mtk_p_sample_step": (C.c_int, [_p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _i32, _p, _p, _i64, _i64, _u64, _u64, _p]),
+    "mtk_gauss_kl_rows": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p]),
     "mtk_quantile_inverse": (C.c_int, [_i32, _i64, _i32, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "mtk_ddim_step": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),
     "mtk_p_sample_step_guided": (C.c_int, [_p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),

@@ -80,6 +80,7 @@ struct mtk_ctx {
     SchedRow* d_rows = nullptr;
     int32_t* d_off = nullptr;
     float* d_logK = nullptr;
+    double* d_kl = nullptr;  // [T][4]: posterior_mean_coef1/2, posterior_log_variance_clipped, model log-variance (KL Gaussian loss; built on first use)
     bool fast_math = false;  // MTK_MATH_FAST: diffusion kernels on hardware transcendentals, exact block LSE
     // denoiser
     bool have_weights = false;

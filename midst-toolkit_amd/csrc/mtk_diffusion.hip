@@ -1147,6 +1147,71 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// KL Gaussian loss (a9, GaussianLossType.KL): _vb_terms_bpd GMD:431-484 with normal_kl DU:9-45 and
+// discretized_gaussian_log_likelihood DU:62-91, EPS parametrisation.  Same promotion as the reference: means and the
+// clipped posterior log-variance are fp32 expressions, the model log-variance is fp64, so everything it touches is.
+// One lane per record; what depends on t alone (two exponentials, the inverse std-dev) is formed once per record.
+// ------------------------------------------------------------------------------------------------
+struct KlArgs {
+    int64_t B;
+    int Nn, T;
+    const SchedRow* rows;
+    const double* tab;  // [T][4]: posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped, model log-variance
+    const float* mo; int64_t mo_rs, mo_cs;
+    const float* x0; int64_t x0_ld;
+    const float* xt; int64_t xt_rs, xt_cs;
+    const int64_t* t;
+    double* loss;
+};
+
+__device__ __forceinline__ double approx_normal_cdf(double v) {  // DU:48-59
+    return 0.5 * (1.0 + tanh(0.79788456080286535588 * (v + 0.044715 * (v * v * v))));
+}
+
+__global__ __launch_bounds__(kBlock) void k_gauss_kl_rows(KlArgs a) {
+    const double inv_ln2 = 1.0 / 0.69314718055994530942;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int t = (int)a.t[row];
+        const SchedRow sr = a.rows[t];
+        const double* tb = a.tab + (size_t)t * 4;
+        const float c1 = (float)tb[0], c2 = (float)tb[1], lv1 = (float)tb[2];
+        const double lv2 = tb[3];
+        const float* mo = a.mo + row * a.mo_rs;
+        const float* xt = a.xt + row * a.xt_rs;
+        const float* x0 = a.x0 + row * a.x0_ld;
+        double acc = 0.0;
+        if (t != 0) {
+            const double head = (-1.0 + lv2) - (double)lv1;
+            const double e1 = exp((double)lv1 - lv2), e2 = exp(-lv2);
+            for (int j = 0; j < a.Nn; ++j) {
+                const float xs = x0[j], xj = xt[j * a.xt_cs], ej = mo[j * a.mo_cs];
+                const float true_mean = c1 * xs + c2 * xj;
+                const float x0_hat = sr.sqrt_recip_acp * xj - sr.sqrt_recipm1_acp * ej;
+                const float mean = c1 * x0_hat + c2 * xj;
+                const float d = true_mean - mean;
+                acc += 0.5 * ((head + e1) + (double)(d * d) * e2);
+            }
+        } else {
+            const double inv_stdv = exp(-(0.5 * lv2));
+            for (int j = 0; j < a.Nn; ++j) {
+                const float xs = x0[j], xj = xt[j * a.xt_cs], ej = mo[j * a.mo_cs];
+                const float x0_hat = sr.sqrt_recip_acp * xj - sr.sqrt_recipm1_acp * ej;
+                const float mean = c1 * x0_hat + c2 * xj;
+                const float centered = xs - mean;
+                const double cdf_plus = approx_normal_cdf(inv_stdv * (double)(centered + (float)(1.0 / 255.0)));
+                const double cdf_min = approx_normal_cdf(inv_stdv * (double)(centered - (float)(1.0 / 255.0)));
+                double p;
+                if (xs < -0.999f) p = cdf_plus;
+                else if (xs > 0.999f) p = 1.0 - cdf_min;
+                else p = cdf_plus - cdf_min;
+                acc -= log(fmax(p, 1e-12));
+            }
+        }
+        a.loss[row] = acc / (double)a.Nn * inv_ln2;
+    }
+}
+
 int max_levels(const mtk_ctx* c) {  // widest categorical block of the table
     int m = 0;
     for (int32_t k : c->K) m = k > m ? k : m;
@@ -1311,6 +1376,32 @@ extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const f
     MTK_HIP(hipSetDevice(ctx->device));
     InitArgs a{ctx->dev(), B, z0, u0, z, z_idx, x_in, xi_rs, xi_cs, seed, row0};
     hipLaunchKernelGGL(k_sample_init, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out, int64_t mo_rs, int64_t mo_cs, const float* x0,
+                                 int64_t x0_ld, const float* x_t, int64_t xt_rs, int64_t xt_cs, const int64_t* t, double* loss,
+                                 mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: null context");
+    if (B < 0 || ctx->Nn < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: negative B or no numeric columns");
+    if (B == 0) return MTK_OK;
+    if (!model_out || !x0 || !x_t || !t || !loss) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: null pointer");
+    if (x0_ld < ctx->Nn) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: x0_ld too small");
+    MTK_HIP(hipSetDevice(ctx->device));
+    if (!ctx->d_kl) {  // per-timestep coefficients of this loss, built on first use
+        std::vector<double> h((size_t)ctx->T * 4);
+        for (int i = 0; i < ctx->T; ++i) {
+            h[(size_t)i * 4 + 0] = ctx->tab(MTK_TAB_POST_COEF1, i);
+            h[(size_t)i * 4 + 1] = ctx->tab(MTK_TAB_POST_COEF2, i);
+            h[(size_t)i * 4 + 2] = ctx->tab(MTK_TAB_POST_LOGVAR_CLIPPED, i);
+            h[(size_t)i * 4 + 3] = ctx->tab(MTK_TAB_MODEL_LOGVAR64, i);
+        }
+        MTK_HIP(hipMalloc(&ctx->d_kl, h.size() * sizeof(double)));
+        MTK_HIP(hipMemcpy(ctx->d_kl, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    KlArgs a{B, ctx->Nn, ctx->T, ctx->d_rows, ctx->d_kl, model_out, mo_rs, mo_cs, x0, x0_ld, x_t, xt_rs, xt_cs, t, loss};
+    hipLaunchKernelGGL(k_gauss_kl_rows, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }

@@ -66,7 +66,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         device = torch.device(device) if device is not None else _default_device()
         num_classes = np.asarray(num_classes)
         # the reference raises ValueError lazily for these enums (GMD:408, 543, 832); do it up front
-        if getattr(gaussian_loss_type, "value", None) != "mse":
+        if getattr(gaussian_loss_type, "value", None) not in ("mse", "kl"):
             raise ValueError(f"Unsupported Gaussian loss type: {gaussian_loss_type}")
         if getattr(gaussian_parametrization, "value", None) != "eps":
             raise ValueError(f"Unsupported Gaussian parametrization: {gaussian_parametrization}")
@@ -100,7 +100,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         self.posterior_mean_coef1 = post["posterior_mean_coef1"].to(device)
         self.posterior_mean_coef2 = post["posterior_mean_coef2"].to(device)
         self._host_tables = {k: v.float() for k, v in buffers.items()}
-        self._host_tables.update({k: post[k] for k in ("posterior_mean_coef1", "posterior_mean_coef2", "model_log_variance", "model_variance")})
+        self._host_tables.update({k: post[k] for k in ("posterior_mean_coef1", "posterior_mean_coef2", "model_log_variance", "model_variance",
+                                                       "posterior_log_variance_clipped")})
         for key, value in buffers.items():
             self.register_buffer(key, value.float().to(device))
 
@@ -154,10 +155,18 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
 
     def _gaussian_loss(self, model_out: Tensor, features_start: Tensor, features_timestep: Tensor, timestep: Tensor,
                        noise: Tensor, model_kwargs: dict[str, Any] | None = None) -> Tensor:
-        """GMD:505, MSE branch: mean_d (noise - model_out)^2 per record."""
+        """GMD:505.  MSE branch: mean_d (noise - model_out)^2 per record (fp32); KL branch (GMD:534-541): the variational
+        bound term of each record in bits per dimension (fp64, like the reference's)."""
         mo = model_out.float().contiguous()
         B, n = mo.shape
         eng = self._aux_engine(n)
+        if getattr(self.gaussian_loss_type, "value", "mse") == "kl":
+            x0, xt = features_start.float().contiguous(), features_timestep.float().contiguous()
+            if x0.shape != mo.shape or xt.shape != mo.shape:
+                raise AssertionError(f"Expected shapes to be equal, but got {tuple(mo.shape)}, {tuple(x0.shape)}, {tuple(xt.shape)}")
+            out = torch.empty((B,), dtype=torch.float64, device=mo.device)
+            eng.gauss_kl_rows(mo, (n, 1), x0, xt, (n, 1), timestep.to(mo.device, torch.int64).contiguous(), out)
+            return out
         out = torch.empty((B,), dtype=torch.float32, device=mo.device)
         eng.loss_rows(mo, (n, 1), None, None, noise.float().contiguous(), timestep.to(mo.device, torch.int64).contiguous(), None, out)
         return out
@@ -212,8 +221,14 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         eng.q_sample(x0, t, eps, u, x_in, (1, B), xt_idx, seed, row0)
         self._denoise_cm(eng, x_in, t, B, out)
         lm = torch.empty((B,), dtype=torch.float32, device=dev) if C > 0 else None
-        lg = torch.empty((B,), dtype=torch.float32, device=dev) if Nn > 0 else None
-        eng.loss_rows(out, (1, B), x0, xt_idx, eps, t, lm, lg, seed, row0)
+        kl = getattr(self.gaussian_loss_type, "value", "mse") == "kl"  # GMD:534: _vb_terms_bpd instead of the MSE, fp64 like the reference's
+        lg = torch.empty((B,), dtype=torch.float64 if kl else torch.float32, device=dev) if Nn > 0 else None
+        if kl and Nn > 0:
+            eng.gauss_kl_rows(out, (1, B), x0, x_in, (1, B), t, lg)
+            if C > 0:
+                eng.loss_rows(out, (1, B), x0, xt_idx, eps, t, lm, None, seed, row0)
+        else:
+            eng.loss_rows(out, (1, B), x0, xt_idx, eps, t, lm, lg, seed, row0)
         zero = torch.zeros((1,)).float()
         return (lm if lm is not None else zero), (lg if lg is not None else zero)
 

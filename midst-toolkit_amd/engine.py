@@ -109,6 +109,13 @@ class Engine:
                                            x0.stride(0) if x0 is not None else 0, ptr(xt_idx), ptr(eps), ptr(t), ptr(loss_multi),
                                            ptr(loss_gauss), seed, row0, self._stream()))
 
+    def gauss_kl_rows(self, model_out, mo_strides, x0, x_t, xt_strides, t, loss):
+        """KL Gaussian loss rows (GaussianLossType.KL, GMD:431-484): ``loss`` is a [B] fp64 tensor."""
+        assert loss.dtype == torch.float64 and x0.stride(1) == 1
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_gauss_kl_rows(self._h, t.shape[0], ptr(model_out), mo_strides[0], mo_strides[1], ptr(x0), x0.stride(0),
+                                               ptr(x_t), xt_strides[0], xt_strides[1], ptr(t), ptr(loss), self._stream()))
+
     def tf_score(self, x: torch.Tensor, noise: torch.Tensor, t_list, add_t: int = 0, precision: str = "fp32",
                  out: torch.Tensor | None = None) -> torch.Tensor:
         require_cuda(x, "tf_score")

@@ -55,6 +55,9 @@ class ClavaDDPMTrainer:
         self.seed = 0  # base seed of the in-kernel noise when diffusion_model.rng == "philox"
 
         net = diffusion_model._denoise_fn
+        if getattr(diffusion_model.gaussian_loss_type, "value", "mse") != "mse":
+            raise ValueError("the HIP training iteration differentiates the MSE Gaussian loss only (every shipped config); "
+                             f"got {diffusion_model.gaussian_loss_type}")
         if getattr(net, "precision", "fp32") != "fp32" or diffusion_model.precision != "fp32":
             raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
         self._engine = diffusion_model.engine()

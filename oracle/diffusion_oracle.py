@@ -556,3 +556,32 @@ def quantile_inverse(x: np.ndarray, quantiles: np.ndarray, references: np.ndarra
         res[lower] = q[0]
         out[:, c] = res
     return out
+
+
+# --------------------------------------------------------------------------- KL Gaussian loss (a9, gaussian_loss_type = KL)
+def gaussian_kl_rows(s: Schedule, model_out: torch.Tensor, x0: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """``_gaussian_loss`` with ``GaussianLossType.KL`` (GMD:534-541 -> ``_vb_terms_bpd`` GMD:431-484, ``normal_kl`` DU:9-45,
+    ``discretized_gaussian_log_likelihood`` DU:62-91, ``approx_standard_normal_cdf`` DU:48-59) for the EPS
+    parametrisation.  Means and the clipped posterior log-variance are fp32, the model's log-variance row is fp64
+    (SURVEY finding 0.4), so every term it touches — and the result — is fp64; promotion is left to torch as in the
+    reference.  Returns per-record bits per dimension: the decoder NLL where ``t == 0``, the KL elsewhere."""
+    col = lambda tab: tab[t][:, None].expand(x_t.shape)  # noqa: E731  (DU:172 extract)
+    true_mean = col(s.posterior_mean_coef1) * x0 + col(s.posterior_mean_coef2) * x_t
+    lv1 = col(s.posterior_log_variance_clipped)
+    x0_hat = col(s.sqrt_recip_alphas_cumprod) * x_t - col(s.sqrt_recipm1_alphas_cumprod) * model_out
+    mean = col(s.posterior_mean_coef1) * x0_hat + col(s.posterior_mean_coef2) * x_t
+    lv2 = col(s.model_log_variance_f64)
+    kl = 0.5 * (-1.0 + lv2 - lv1 + torch.exp(lv1 - lv2) + ((true_mean - mean) ** 2) * torch.exp(-lv2))
+    kl = kl.mean(dim=1) / np.log(2.0)
+    log_scales = 0.5 * lv2
+    centered = x0 - mean
+    inv_stdv = torch.exp(-log_scales)
+    cdf = lambda v: 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (v + 0.044715 * torch.pow(v, 3))))  # noqa: E731
+    cdf_plus = cdf(inv_stdv * (centered + 1.0 / 255.0))
+    cdf_min = cdf(inv_stdv * (centered - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    log_probs = torch.where(x0 < -0.999, log_cdf_plus,
+                            torch.where(x0 > 0.999, log_one_minus_cdf_min, torch.log((cdf_plus - cdf_min).clamp(min=1e-12))))
+    nll = (-log_probs).mean(dim=1) / np.log(2.0)
+    return torch.where(t == 0, nll, kl)

@@ -590,6 +590,42 @@ def test_fast_math_against_oracle(tag, monkeypatch):
         check_categorical(zid.t(), want_zi, logp, uu, c["K"])
 
 
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed"])
+def test_gaussian_kl_loss(tag):
+    """GaussianLossType.KL through the C ABI (mtk_gauss_kl_rows) against the reference's own per-record values
+    (tests/golden/kl_*.npz; the oracle equals them bit for bit): fp64 arithmetic on both sides, 1e-4 relative is the
+    north-star bar, measured ~1e-9.  Then the drop-in mixed_loss with the loss type set, the reference's draws injected."""
+    import os
+
+    import midst_toolkit_amd as mtk
+
+    c = load_case(tag)
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", f"kl_{tag}.npz"))
+    Nn, B = c["Nn"], c["x0"].shape[0]
+    d = build(c)
+    d.gaussian_loss_type = mtk.GaussianLossType.KL
+    x0, mo, xt, t = tt(c["x0"])[:, :Nn], tt(c["ml_model_out"])[:, :Nn], tt(c["ml_x_num_t"]), tt(c["ml_t"])
+    for name, tv in (("t", t), ("t0", torch.zeros_like(t)), ("t1", torch.ones_like(t))):
+        got = d._gaussian_loss(mo.to(dev()), x0.to(dev()), xt.to(dev()), tv.to(dev()), torch.zeros_like(mo).to(dev()))
+        assert got.dtype == torch.float64 and got.shape == (B,)
+        close(got, torch.from_numpy(k[f"kl_rows_{name}"]), rtol=1e-7, atol=1e-9)
+    # whole path: q_sample -> denoiser (fp32 MFMA) -> KL rows, same timesteps and noise as the reference's call
+    uni = tt(c["ml_u"]).to(dev()) if c["C"] else None  # categorical draws do not enter the Gaussian term's inputs' numeric block
+    lm, lg = d.mixed_loss_rows(tt(c["x0"]).to(dev()), timestep=torch.from_numpy(k["call_t"]).to(dev()),
+                               noise=torch.from_numpy(k["call_eps"]).to(dev()), uniform=uni)
+    assert lg.dtype == torch.float64
+    if c["C"] == 0:  # with categorical columns the denoiser input depends on the reference's uniforms of that call, which the fixture does not hold
+        want = float(k["call_means"][1])
+        assert abs(float(lg.mean().cpu()) - want) <= RTOL * abs(want)
+    with pytest.raises(ValueError):
+        mtk.ClavaDDPMTrainer(d, None, 1e-3, 0.0, 1, device=dev())
+    # strided (column-major) operands through the engine: identical values
+    eng = d._aux_engine(Nn)
+    out2 = torch.empty((B,), dtype=torch.float64, device=dev())
+    eng.gauss_kl_rows(colmajor(mo), (1, B), x0.contiguous().to(dev()), colmajor(xt), (1, B), t.to(dev()), out2)
+    assert torch.equal(out2, d._gaussian_loss(mo.to(dev()), x0.to(dev()), xt.to(dev()), t.to(dev()), torch.zeros_like(mo).to(dev())))
+
+
 def test_fast_math_wide_blocks(monkeypatch):
     """Blocks wider than the small register cache (12): 14 and 16 levels take the 16-column cached kernels, 20 levels the
     streaming pass.  Same checks as above with a random denoiser output, plus the in-kernel-noise draws stay in range."""

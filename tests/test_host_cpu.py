@@ -65,8 +65,12 @@ def test_no_cpu_path():
 def test_unsupported_enums_raise_value_error():
     dp = mtk.DiffusionParameters([16], 0.0)
     net = mtk.MLPDiffusion(4, 0, mtk.IsTargetConditioned.NONE, dp)
+    kl = mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_loss_type=mtk.GaussianLossType.KL, device=torch.device("cpu"))
+    assert kl.gaussian_loss_type is mtk.GaussianLossType.KL  # both loss types of GMD:531-543 are served
     with pytest.raises(ValueError):
-        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_loss_type=mtk.GaussianLossType.KL, device=torch.device("cpu"))
+        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_loss_type="huber", device=torch.device("cpu"))
+    with pytest.raises(ValueError):
+        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_parametrization=mtk.GaussianParametrization.X0, device=torch.device("cpu"))
     with pytest.raises(ValueError):
         mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, parametrization=mtk.Parametrization.DIRECT, device=torch.device("cpu"))
 

@@ -157,3 +157,27 @@ def test_scan_recurrence_equals_logcumsumexp():
     for r in range(un.shape[0]):
         got = orc.scan_lse_scalar(un[r].numpy(), off)
         assert np.array_equal(got, want[r].numpy()), r
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed"])
+def test_gaussian_kl_rows_bit_exact(tag):
+    """GaussianLossType.KL (GMD:431-484): the restatement equals the reference's _gaussian_loss bit for bit (fp64) on the
+    stored batch, with t = 0 everywhere (decoder NLL) and with t = 1 everywhere (tests/golden/kl_*.npz)."""
+    import os
+
+    c = load_case(tag)
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", f"kl_{tag}.npz"))
+    Nn = c["Nn"]
+    s = orc.make_schedule(c["T"], c["sched"])
+    x0, mo, xt, t = tt(c["x0"])[:, :Nn], tt(c["ml_model_out"])[:, :Nn], tt(c["ml_x_num_t"]), tt(c["ml_t"])
+    for name, tv in (("t", t), ("t0", torch.zeros_like(t)), ("t1", torch.ones_like(t))):
+        got = orc.gaussian_kl_rows(s, mo, x0, xt, tv)
+        assert got.dtype == torch.float64
+        assert torch.equal(got, torch.from_numpy(k[f"kl_rows_{name}"])), name
+    # the whole reference call: same draws -> same Gaussian mean (the denoiser runs on this host's BLAS: 1e-6)
+    tc, eps = torch.from_numpy(k["call_t"]), torch.from_numpy(k["call_eps"])
+    if c["C"] == 0:
+        x_t = s.sqrt_alphas_cumprod[tc][:, None] * x0 + s.sqrt_one_minus_alphas_cumprod[tc][:, None] * eps
+        out = orc.mlp_forward(case_params(c), x_t, tc)
+        mean = float(orc.gaussian_kl_rows(s, out, x0, x_t, tc).mean())
+        assert abs(mean - float(k["call_means"][1])) <= 1e-6 * abs(float(k["call_means"][1]))

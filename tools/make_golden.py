@@ -429,7 +429,43 @@ def gen_quantile():
         print(f"quantile {tag}: n_quantiles={qt.n_quantiles_} columns={train.shape[1]}")
 
 
+def gen_kl(tag):
+    """The KL Gaussian loss (gaussian_loss_type=KL: GMD:431-484 _vb_terms_bpd, DU:9-91) on the inputs the case fixture
+    already holds (x0, t, x_t, model_out of the reference's own mixed_loss replay): per-record values for the stored t,
+    for t = 0 everywhere (decoder NLL) and t = 1 everywhere, and the two means of a whole mixed_loss call."""
+    z = np.load(os.path.join(OUT, f"case_{tag}.npz"))
+    K, Nn, T, d_layers, sched = z["K"], int(z["Nn"]), int(z["T"]), list(z["d_layers"]), str(z["sched"])
+    diff, _ = build(K, Nn, d_layers, T, sched)
+    diff.gaussian_loss_type = gmd.GaussianLossType.KL
+    x0 = torch.from_numpy(z["x0"])
+    B = x0.shape[0]
+    mo = torch.from_numpy(z["ml_model_out"])[:, :Nn]
+    xt = torch.from_numpy(z["ml_x_num_t"])
+    t = torch.from_numpy(z["ml_t"])
+    eps = torch.from_numpy(z["ml_eps"])
+    out = {}
+    with torch.no_grad():
+        for name, tv in (("t", t), ("t0", torch.zeros_like(t)), ("t1", torch.ones_like(t))):
+            rows = diff._gaussian_loss(mo, x0[:, :Nn], xt, tv, eps)
+            assert rows.dtype == torch.float64 and rows.shape == (B,)
+            out[f"kl_rows_{name}"] = rows.numpy()
+        log: list = []
+        torch.manual_seed(1234)
+        with capture_rng(log):
+            m_mean, g_mean = diff.mixed_loss(x0, {"y": torch.zeros(B, dtype=torch.long)})
+    out["call_t"] = log[0][1].numpy()
+    out["call_eps"] = log[1][1].numpy()
+    out["call_means"] = np.array([float(m_mean), float(g_mean)], dtype=np.float64)
+    out["call_gauss_dtype"] = np.array(str(g_mean.dtype))
+    np.savez_compressed(os.path.join(OUT, f"kl_{tag}.npz"), **out)
+    print(f"kl {tag}: rows dtype float64, mixed_loss gauss mean {float(g_mean):.6g} ({g_mean.dtype})")
+
+
 def main():
+    if "--kl-only" in sys.argv:
+        for tag in ("A_numeric", "B_ragged", "M_mixed"):
+            gen_kl(tag)
+        return
     if "--quantile-only" in sys.argv:
         gen_quantile()
         return
@@ -448,6 +484,8 @@ def main():
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         gen_loader()
         gen_quantile()
+        for tag in ("A_numeric", "B_ragged", "M_mixed"):
+            gen_kl(tag)
         gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
         gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
