@@ -241,9 +241,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
             read_frags(F1, xi, wi, 3);
             mfma_all(F0);
             STAMP(st_b);
-            // next block landed (this wave's share); F1 is in registers.  The first wait of a tile is a full one: the
-            // previous tile's stores are outstanding too, and stores and loads do not return in order with each other.
-            if (kb != 0 && x_tail) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::XPW) : "memory");
+            // next block landed (this wave's share); F1 is in registers.  The previous tile's stores may be outstanding
+            // too and do not return in order with the loads, but the count still holds: with S stores, the weight
+            // pieces and XPW younger record pieces in flight, "at most XPW outstanding" needs S + WPW completions, and
+            // fewer than WPW loads done (they return in order: weights first) would leave at most S + WPW - 1.
+            if (x_tail) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G::XPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();  // ... everyone's share, and this block's buffers have no readers left
 #ifdef DIAG_STAMPS
