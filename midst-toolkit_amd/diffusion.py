@@ -105,6 +105,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         for key, value in buffers.items():
             self.register_buffer(key, value.float().to(device))
 
+        self.results_on_device = False  # True: sample / sample_all return device tensors (the reference moves them to the CPU, GMD:1423),
+        #                                 so that e.g. transforms.QuantileInverse runs on them without a host round trip
         self.rng = "torch"  # "torch": draw like the reference does; "philox": draw inside the kernels
         self.math = None    # None: "fast" with rng="philox", "reference" otherwise; or force "reference"/"fast"
         self.precision = getattr(denoise_fn, "precision", "fp32")
@@ -293,7 +295,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed, grad=grad)
         sample = torch.empty((B, Nn + C), dtype=torch.float64, device=dev)
         eng.sample_decode(B, z, z_idx, sample)
-        return sample.float().cpu() if ddim else sample.cpu()  # the reference's DDIM chain is fp32 end to end
+        sample = sample.float() if ddim else sample  # the reference's DDIM chain is fp32 end to end
+        return sample if getattr(self, "results_on_device", False) else sample.cpu()
 
     @torch.no_grad()
     def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
@@ -344,7 +347,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             sample, outputs = sample_fn(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function)
             mask_nan = torch.any(sample.isnan(), dim=1)
             sample = sample[~mask_nan]
-            outputs["y"] = outputs["y"].cpu()[~mask_nan]
+            outputs["y"] = outputs["y"].to(sample.device)[~mask_nan]
             all_samples.append(sample)
             all_targets.append(outputs["y"])
             if sample.shape[0] != batch_size:

@@ -99,3 +99,25 @@ def test_gpu_inverse_uniform_empty_and_large():
     assert torch.equal(a, b)
     q = torch.from_numpy(z["quantiles"]).to(dev)
     assert bool((out >= q[0]).all()) and bool((out <= q[-1]).all())
+
+
+@pytest.mark.gpu
+def test_sampled_rows_stay_on_device_through_the_inverse_transform():
+    """results_on_device: sample_all hands back device tensors (same values as the CPU return of the reference-shaped call,
+    same torch draws), and QuantileInverse maps their numeric block without a host copy."""
+    import midst_toolkit_amd as mtk
+
+    z = load("small")
+    dev = torch.device("cuda:0")
+    n = z["quantiles"].shape[1]
+    net = mtk.MLPDiffusion(n, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+    d = mtk.GaussianMultinomialDiffusion(np.array([0]), n, net, num_timesteps=20, device=dev).to(dev)
+    torch.manual_seed(3)
+    x_cpu, y_cpu = d.sample_all(96, 48, torch.ones(1))
+    d.results_on_device = True
+    torch.manual_seed(3)
+    x_dev, y_dev = d.sample_all(96, 48, torch.ones(1))
+    assert x_dev.is_cuda and y_dev.is_cuda and not x_cpu.is_cuda
+    assert torch.equal(x_dev.cpu(), x_cpu) and torch.equal(y_dev.cpu(), y_cpu)
+    got = mtk.QuantileInverse(_Fitted(z), dev).inverse_transform(x_dev[:, :n]).cpu().numpy()
+    _check(got, orc.quantile_inverse(x_cpu.numpy()[:, :n], z["quantiles"], z["references"], True), z["quantiles"])
