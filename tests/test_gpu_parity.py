@@ -417,7 +417,7 @@ def test_mlp_forward_bf16(tag):
         assert torch.equal(o, out[:n]), n
 
 
-@pytest.mark.parametrize("shape", [(120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512]), (40, [128, 256])])
+@pytest.mark.parametrize("shape", [(120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512]), (40, [128, 256]), (200, [1536, 768, 2048])])
 def test_mlp_forward_bf16_layered(shape):
     """Denoiser shapes outside the fused kernel (hidden width != 512, unequal widths, D > 128) run layer by layer
     on bf16 MFMA: same bars as the fused kernel."""
