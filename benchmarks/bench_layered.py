@@ -39,7 +39,7 @@ def main():
     torch.cuda.synchronize()
     secs = float(np.median([s.elapsed_time(e) for s, e in ev])) * 1e-3
     fl = 2 * (D * 128 + 128 * a.hidden + 3 * a.hidden ** 2 + a.hidden * D)
-    print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("MTK_LIB_PATH", "libmtk_hip.so")), "chunk": os.environ.get("MTK_LAYERED_CHUNK", "131072"),
+    print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("MTK_LIB_PATH", "libmtk_hip.so")), "chunk": os.environ.get("MTK_LAYERED_CHUNK", "auto"),
                       "rows": B, "hidden": a.hidden, "ms": secs * 1e3, "TFLOP/s": B * fl / secs / 1e12, "frac_of_peak": B * fl / secs / 2.5e15}), flush=True)
 
 
