@@ -148,6 +148,16 @@ __device__ __forceinline__ void mtk_normal2(uint32_t a, uint32_t b, float& n0, f
     n0 = r * c;
     n1 = r * s;
 }
+// element j & 3 of (a, b, c, d) by masks.  A select chain over the members of a uint4 (or four floats of a struct) is
+// turned into a dynamically indexed stack slot by the compiler: a scratch store, load and vmcnt wait per use.
+__device__ __forceinline__ uint32_t mtk_pick4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, int j) {
+    const uint32_t m1 = 0u - (uint32_t)(j & 1), m2 = 0u - (uint32_t)((j >> 1) & 1);
+    const uint32_t lo = (a & ~m1) | (b & m1), hi = (c & ~m1) | (d & m1);
+    return (lo & ~m2) | (hi & m2);
+}
+__device__ __forceinline__ float mtk_pick4f(float a, float b, float c, float d, int j) {
+    return __uint_as_float(mtk_pick4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d), j));
+}
 enum { MTK_STREAM_EPS = 1, MTK_STREAM_U = 2, MTK_STREAM_Z0 = 3, MTK_STREAM_U0 = 4, MTK_STREAM_STEP = 16 };
 // element j of the normal stream for `row`
 __device__ __forceinline__ float mtk_philox_normal(uint64_t seed, uint64_t row, uint32_t stream, int j) {
@@ -158,7 +168,6 @@ __device__ __forceinline__ float mtk_philox_normal(uint64_t seed, uint64_t row, 
 }
 __device__ __forceinline__ float mtk_philox_uniform(uint64_t seed, uint64_t row, uint32_t stream, int j) {
     const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(j >> 2), stream, seed);
-    const uint32_t w = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
-    return mtk_u01(w);
+    return mtk_u01(mtk_pick4(r.x, r.y, r.z, r.w, j));
 }
 #endif

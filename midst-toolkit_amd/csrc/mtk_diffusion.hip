@@ -71,15 +71,15 @@ struct PhiloxU {
     uint64_t seed, row;
     uint32_t stream;
     int have;
-    uint4 r;
+    uint32_t r0, r1, r2, r3;
     __device__ __forceinline__ PhiloxU(uint64_t s, uint64_t rw, uint32_t st) : seed(s), row(rw), stream(st), have(-1) {}
     __device__ __forceinline__ float uniform(int j) {
         if ((j >> 2) != have) {
             have = j >> 2;
-            r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+            const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+            r0 = r.x; r1 = r.y; r2 = r.z; r3 = r.w;
         }
-        const uint32_t w = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
-        return mtk_u01(w);
+        return mtk_u01(mtk_pick4(r0, r1, r2, r3, j));
     }
 };
 struct PhiloxN {
@@ -95,7 +95,7 @@ struct PhiloxN {
             mtk_normal2(r.x, r.y, n0, n1);
             mtk_normal2(r.z, r.w, n2, n3);
         }
-        return (j & 2) ? ((j & 1) ? n3 : n2) : ((j & 1) ? n1 : n0);
+        return mtk_pick4f(n0, n1, n2, n3, j);
     }
 };
 
@@ -525,7 +525,7 @@ struct PhiloxNF {
             normal2_fast(r.x, r.y, n0, n1);
             normal2_fast(r.z, r.w, n2, n3);
         }
-        return (j & 2) ? ((j & 1) ? n3 : n2) : ((j & 1) ? n1 : n0);
+        return mtk_pick4f(n0, n1, n2, n3, j);
     }
 };
 
@@ -534,15 +534,15 @@ struct PhiloxW {
     uint64_t seed, row;
     uint32_t stream;
     int have;
-    uint4 r;
+    uint32_t r0, r1, r2, r3;
     __device__ __forceinline__ PhiloxW(uint64_t s, uint64_t rw, uint32_t st) : seed(s), row(rw), stream(st), have(-1) {}
     __device__ __forceinline__ float uniform(int j) {
         if ((j >> 2) != have) {
             have = j >> 2;
-            r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+            const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)have, stream, seed);
+            r0 = r.x; r1 = r.y; r2 = r.z; r3 = r.w;
         }
-        const uint32_t w = (j & 2) ? ((j & 1) ? r.w : r.z) : ((j & 1) ? r.y : r.x);
-        return mtk_u01(w);
+        return mtk_u01(mtk_pick4(r0, r1, r2, r3, j));  // by masks: see mtk_pick4
     }
 };
 
