@@ -46,33 +46,57 @@ struct G2 {
 // are too few workgroups per CU to hide a global round trip per k-block any other way).
 template <bool TR, int T>
 struct TileMover {
-    static constexpr int NLD = T * TK / 4 / 256;  // float4 per thread
+    static constexpr int NLD = T * TK / 4 / 256;  // float4 per thread: 2 (T = 64) or 4 (T = 128)
     static constexpr int LDT = T + 4;             // transposed tile in LDS: [32][T + 4]
-    float4 r[NLD];
-    __device__ __forceinline__ void load(const float* src, int64_t ld, int64_t r0, int k0, int tid) {
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int idx = tid + 256 * q;
-            if (!TR) {
-                const int rr = idx >> 3, c = (idx & 7) * 4;
-                r[q] = *reinterpret_cast<const float4*>(src + (r0 + rr) * ld + k0 + c);
-            } else {
-                const int kk = idx / (T / 4), r4 = (idx % (T / 4)) * 4;
-                r[q] = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + kk) * ld + r0 + r4);
-            }
+    static_assert(NLD == 2 || NLD == 4, "tile sizes 64 and 128");
+    // Named registers, not an array: as `float4 r[NLD]` the prefetch lived in a stack slot (scratch_store right after
+    // each global load, behind a vmcnt wait, and scratch_load + vmcnt(0) before each LDS write), which serialised the
+    // global round trip the prefetch is there to hide.
+    typedef float v4f __attribute__((ext_vector_type(4)));  // native vector: HIP's float4 (a union type) kept the struct in memory
+    v4f r0, r1, r2, r3;
+    template <int Q>
+    __device__ __forceinline__ v4f& reg() {
+        if constexpr (Q == 0) return r0;
+        else if constexpr (Q == 1) return r1;
+        else if constexpr (Q == 2) return r2;
+        else return r3;
+    }
+    template <int Q>
+    __device__ __forceinline__ void load_q(const float* src, int64_t ld, int64_t row0, int k0, int tid) {
+        const int idx = tid + 256 * Q;
+        if (!TR) {
+            const int rr = idx >> 3, c = (idx & 7) * 4;
+            reg<Q>() = *reinterpret_cast<const v4f*>(src + (row0 + rr) * ld + k0 + c);
+        } else {
+            const int kk = idx / (T / 4), r4 = (idx % (T / 4)) * 4;
+            reg<Q>() = *reinterpret_cast<const v4f*>(src + (int64_t)(k0 + kk) * ld + row0 + r4);
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) const {
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int idx = tid + 256 * q;
-            if (!TR) {
-                const int rr = idx >> 3, c = (idx & 7) * 4;
-                *reinterpret_cast<float4*>(&lds[rr * LDN + c]) = r[q];
-            } else {
-                const int kk = idx / (T / 4), r4 = (idx % (T / 4)) * 4;
-                *reinterpret_cast<float4*>(&lds[kk * LDT + r4]) = r[q];
-            }
+    template <int Q>
+    __device__ __forceinline__ void store_q(float* lds, int tid) {
+        const int idx = tid + 256 * Q;
+        if (!TR) {
+            const int rr = idx >> 3, c = (idx & 7) * 4;
+            *reinterpret_cast<v4f*>(&lds[rr * LDN + c]) = reg<Q>();
+        } else {
+            const int kk = idx / (T / 4), r4 = (idx % (T / 4)) * 4;
+            *reinterpret_cast<v4f*>(&lds[kk * LDT + r4]) = reg<Q>();
+        }
+    }
+    __device__ __forceinline__ void load(const float* src, int64_t ld, int64_t row0, int k0, int tid) {
+        load_q<0>(src, ld, row0, k0, tid);
+        load_q<1>(src, ld, row0, k0, tid);
+        if constexpr (NLD == 4) {
+            load_q<2>(src, ld, row0, k0, tid);
+            load_q<3>(src, ld, row0, k0, tid);
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, int tid) {
+        store_q<0>(lds, tid);
+        store_q<1>(lds, tid);
+        if constexpr (NLD == 4) {
+            store_q<2>(lds, tid);
+            store_q<3>(lds, tid);
         }
     }
     // lane (li, hh) takes k in [16 hh, 16 hh + 16) of the K block for both operands
