@@ -168,10 +168,14 @@ __device__ __forceinline__ void consume_chunk(P& p, bf16x8 (&w0)[kGrp], bf16x8 (
 typedef __attribute__((address_space(3))) const float lds_f;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f32x4_t lds_f4;
-__device__ __forceinline__ unsigned lds_base(const float* p) {
-    unsigned off = (unsigned)(uintptr_t)(lds_f*)p;
-    asm volatile("" : "+v"(off));
-    return off;
+// The row pointer is uniform; the lane's share (16 bytes per lane half) goes through an opaque copy and is added
+// AFTER it, so the sum is re-formed at every use (one v_add) instead of being hoisted out of the tile loop as a
+// loop-invariant register, which at 512 registers got spilled and reloaded behind a vmcnt(0).
+__device__ __forceinline__ unsigned lds_base(const float* p_uniform, int hh) {
+    const unsigned off = (unsigned)(uintptr_t)(lds_f*)p_uniform;
+    unsigned lane_part = 16u * (unsigned)hh;
+    asm volatile("" : "+v"(lane_part));
+    return off + lane_part;
 }
 __device__ __forceinline__ f32x16 load16_lds(unsigned base, int elem) {  // base + 4 (elem + {0..3, 8..11, 16..19, 24..27})
     f32x16 v;
@@ -216,7 +220,7 @@ __device__ __forceinline__ void pack_out(const f32x16& v, bf16x8& lo, bf16x8& hi
 template <int KS, int NT, int CHUNKS, bool RELU, int NT_NEXT, class PIPE, int NIN, int NOUT, int NACC>
 __device__ __forceinline__ void dense(PIPE& p, bf16x8 (&w0)[kGrp], bf16x8 (&w1)[kGrp], const bf16x8 (&Xin)[NIN], bf16x8 (&Xout)[NOUT],
                                       f32x16 (&acc)[NACC], const float* next_bias, int hh) {
-    const unsigned nb = lds_base(next_bias + 4 * hh);
+    const unsigned nb = lds_base(next_bias, hh);
     // epilogue of one finished tile: ReLU, cvt to bf16 into the activation array, accumulator <- next bias
     auto finish = [&](auto tc) {
         constexpr int nt = decltype(tc)::value;
@@ -306,8 +310,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         const int bytes = (int)((((P == 1) ? r1 : r1 / P) - rec0 + 1) * a.x_ld * 4);  // multiple of 16: x_ld % 4 == 0
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a.x + rec0 * a.x_ld);
         const unsigned sx_off = (unsigned)(reinterpret_cast<unsigned char*>(sx) - mtk_smem_f);
+        int l16 = lane * 16;  // opaque per call: `src + lane * 16` is otherwise hoisted as a 64-bit per-lane pointer and spilled
+        asm volatile("" : "+v"(l16));
         for (int q = wid; q * 1024 < bytes; q += 4)
-            if (q * 1024 + lane * 16 < bytes) dma16(src + q * 1024 + lane * 16, sx_off + q * 1024);
+            if (q * 1024 + l16 < bytes) dma16(src + q * 1024 + l16, sx_off + q * 1024);
         if (wid == 3 && lane < kDimT / 4) {
             const int t = a.t_list[k];
             dma16(reinterpret_cast<const unsigned char*>(a.embb + (int64_t)t * a.emb_ld) + lane * 16,
@@ -341,7 +347,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         Where w;
         w.kk = 0; w.pp = 0; w.rl = 0; w.xoff = 0;
         if (MODE == 0) {
-            w.row = tile * 128 + wid * 32 + li;
+            // the lane's row inside the tile goes through an opaque copy: left visible, its 64-bit image, the address of
+            // its timestep and its share of the emb row address are loop invariants that get hoisted and spilled
+            int lrow = wid * 32 + li;
+            asm volatile("" : "+v"(lrow));
+            w.row = tile * 128 + lrow;
             w.valid = tile < n_tiles && w.row < a.rows;
             w.xoff = w.row * a.x_rs;
         } else {  // 32-bit arithmetic (the host checks BP * P and the tile count fit): 64-bit divisions cost hundreds of cycles
@@ -395,9 +405,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     };
     auto request_emb = [&](int t) {  // proj accumulators <- emb[t] + proj bias (MODE:614), straight from the table
-        const float* er = a.embb + (int64_t)t * a.emb_ld;
+        int h4 = 4 * hh;
+        asm volatile("" : "+v"(h4));
+        const float* er = a.embb + (int64_t)t * a.emb_ld + h4;
         static_for<kDimT / 32>([&](auto ic) {
-            acc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value + 4 * hh);
+            acc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value);
             PIN();
         });
     };
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                     XI[ks][j] = (__bf16)v;
                 }
             });
-            const unsigned eb = lds_base(semb + 4 * hh);
+            const unsigned eb = lds_base(semb, hh);
             static_for<kDimT / 32>([&](auto ic) {  // proj accumulators <- emb[t] + proj bias, from the staged row
                 acc[decltype(ic)::value] = load16_lds(eb, 32 * decltype(ic)::value);
                 PIN();
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         float sq = 0.0f;
         static_for<DT>([&](auto tc) {
             constexpr int nt = decltype(tc)::value;
-            acc[HA] = load16_lds(lds_base(sb + 4 * hh), 32 * nt);
+            acc[HA] = load16_lds(lds_base(sb, hh), 32 * nt);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[HA + 1][r] = acc[HA + 2][r] = acc[HA + 3][r] = 0.0f;
             // four independent accumulation chains over k (a single chain would wait out the MFMA latency)
