@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--train-steps", type=int, default=50)
+    ap.add_argument("--rng", default="philox", help="philox: in-kernel noise; torch: the reference's draws (the drop-in default)")
+    ap.add_argument("--train-only", action="store_true")
     a = ap.parse_args()
     import midst_toolkit_amd as mtk
 
@@ -38,12 +40,12 @@ def main():
         net.precision = precision
         d = mtk.GaussianMultinomialDiffusion(np.asarray(K), Nn, net, num_timesteps=a.T, device=dev).to(dev)
         d.precision = precision
-        d.rng = "philox"
+        d.rng = a.rng
         return d
 
     fl_fwd = 2 * (D * 128 + 128 * a.hidden + 3 * a.hidden * a.hidden + a.hidden * D)
     # ---- reverse sampling: rows / s at T steps (config 4)
-    for prec in ("bf16", "fp32"):
+    for prec in (() if a.train_only else ("bf16", "fp32")):
         d = make(prec)
         rows = a.rows if prec == "bf16" else max(a.rows // 8, 1024)
         d.sample(1024, torch.ones(1))  # warm-up
@@ -66,7 +68,7 @@ def main():
 
     tr = mtk.ClavaDDPMTrainer(d, batches(), 2e-4, 1e-4, a.train_steps, device=dev)
     tr.log_every = 10**9
-    for _ in range(3):
+    for _ in range(6):
         tr._train_step(x0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -75,7 +77,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.train_steps
     fl_step = a.batch * (3 * fl_fwd - 2 * D * 128)
-    print(json.dumps({"measure": "training iteration", "precision": "fp32", "hidden": a.hidden, "batch": a.batch, "ms_per_step": dt * 1e3,
+    print(json.dumps({"measure": "training iteration", "precision": "fp32", "rng": a.rng, "hidden": a.hidden, "batch": a.batch, "ms_per_step": dt * 1e3,
                       "rows_per_s": a.batch / dt, "TFLOPs": fl_step / dt / 1e12, "frac_of_f32_mfma_peak": fl_step / dt / 1e12 / 157.3}), flush=True)
 
 
