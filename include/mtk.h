@@ -197,6 +197,12 @@ int mtk_quantile_inverse(int device, int64_t B, int n_columns, const double* x, 
                          const double* references, int n_quantiles, int output_normal, double* out, int64_t out_ld,
                          mtk_stream stream);
 
+/* The same seam for the other two normalisers the reference can fit (common/dataset_transformations.py:66-69), in
+ * scikit-learn's operation order: kind 0 = StandardScaler.inverse_transform, out = x * p0 + p1 (p0 = scale_, p1 = mean_);
+ * kind 1 = MinMaxScaler.inverse_transform, out = (x - p0) / p1 (p0 = min_, p1 = scale_).  p0, p1: [n_columns] fp64. */
+int mtk_affine_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, int kind, const double* p0,
+                       const double* p1, double* out, int64_t out_ld, mtk_stream stream);
+
 /* Replaces _gaussian_loss with GaussianLossType.KL (GMD:534-541 -> _vb_terms_bpd GMD:431-484; normal_kl DU:9-45,
  * discretized_gaussian_log_likelihood DU:62-91) for the EPS parametrisation: per record, in bits per dimension, the
  * decoder NLL where t == 0 and KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) elsewhere.  model_out / x_t: the numeric block

@@ -21,4 +21,4 @@ from .schedule import SchedulerType, betas_for_alpha_bar, get_named_beta_schedul
 from .scoring import mixed_loss as tartan_federer_mixed_loss  # noqa: F401
 from .scoring import score_records  # noqa: F401
 from .trainer import ClavaDDPMTrainer, update_ema  # noqa: F401
-from .transforms import QuantileInverse  # noqa: F401
+from .transforms import AffineInverse, QuantileInverse, inverse_transform_for  # noqa: F401

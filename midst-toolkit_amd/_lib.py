@@ -40,6 +40,7 @@ _SIGS = {
     "mtk_tf_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _i32, _p, _i32, _p]),
     "mtk_p_sample_step": (C.c_int, [_p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _i32, _p, _p, _i64, _i64, _u64, _u64, _p]),
     "mtk_gauss_kl_rows": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _p, _p, _p]),
+    "mtk_affine_inverse": (C.c_int, [_i32, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "mtk_quantile_inverse": (C.c_int, [_i32, _i64, _i32, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "mtk_ddim_step": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),
     "mtk_p_sample_step_guided": (C.c_int, [_p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),

@@ -68,7 +68,35 @@ __global__ __launch_bounds__(256) void k_quantile_inverse(QinvArgs a) {
     }
 }
 
+// StandardScaler.inverse_transform (x * scale_ + mean_) and MinMaxScaler.inverse_transform ((x - min_) / scale_): the other
+// two normalisers of common/dataset_transformations.py:66-69, each in scikit-learn's own operation order (two roundings).
+__global__ __launch_bounds__(256) void k_affine_inverse(int64_t B, int ncol, int minmax, const double* x, int64_t x_ld, const double* p0,
+                                                        const double* p1, double* out, int64_t o_ld) {
+    const int64_t total = B * ncol;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ncol;
+        const int c = (int)(i - r * ncol);
+        const double v = x[r * x_ld + c];
+        out[r * o_ld + c] = minmax ? (v - p0[c]) / p1[c] : v * p0[c] + p1[c];
+    }
+}
+
 }  // namespace
+
+extern "C" int mtk_affine_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, int kind, const double* p0,
+                                  const double* p1, double* out, int64_t out_ld, mtk_stream stream) {
+    if (B < 0 || n_columns < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_affine_inverse: bad shape");
+    if (kind != 0 && kind != 1) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_affine_inverse: kind = %d (0 = standard, 1 = min-max)", kind);
+    if (B == 0) return MTK_OK;
+    if (!x || !p0 || !p1 || !out) MTK_FAIL(MTK_ERR_ARG, "mtk_affine_inverse: null pointer");
+    if (x_ld < n_columns || out_ld < n_columns) MTK_FAIL(MTK_ERR_ARG, "mtk_affine_inverse: leading dimension below n_columns");
+    MTK_HIP(hipSetDevice(device));
+    int64_t grid = (B * n_columns + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_affine_inverse, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, B, n_columns, kind, x, x_ld, p0, p1, out, out_ld);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
 
 extern "C" int mtk_quantile_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, const double* quantiles,
                                     const double* references, int n_quantiles, int output_normal, double* out, int64_t out_ld,

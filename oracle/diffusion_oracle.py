@@ -585,3 +585,20 @@ def gaussian_kl_rows(s: Schedule, model_out: torch.Tensor, x0: torch.Tensor, x_t
                             torch.where(x0 > 0.999, log_one_minus_cdf_min, torch.log((cdf_plus - cdf_min).clamp(min=1e-12))))
     nll = (-log_probs).mean(dim=1) / np.log(2.0)
     return torch.where(t == 0, nll, kl)
+
+
+def affine_inverse(x: np.ndarray, kind: str, p0: np.ndarray, p1: np.ndarray) -> np.ndarray:
+    """``inverse_transform`` of the reference's other normalisers (common/dataset_transformations.py:66-69), in
+    scikit-learn 1.7.2's operation order: ``standard`` = StandardScaler (``X *= scale_; X += mean_``: p0 = scale_,
+    p1 = mean_), ``minmax`` = MinMaxScaler (``X -= min_; X /= scale_``: p0 = min_, p1 = scale_).  Pinned by
+    tests/golden/affine.npz (outputs of the fitted objects)."""
+    x = np.array(x, dtype=np.float64, copy=True)
+    if kind == "standard":
+        x *= p0
+        x += p1
+    elif kind == "minmax":
+        x -= p0
+        x /= p1
+    else:
+        raise ValueError(f"Unsupported normalization: {kind}")
+    return x

@@ -121,3 +121,45 @@ def test_sampled_rows_stay_on_device_through_the_inverse_transform():
     assert torch.equal(x_dev.cpu(), x_cpu) and torch.equal(y_dev.cpu(), y_cpu)
     got = mtk.QuantileInverse(_Fitted(z), dev).inverse_transform(x_dev[:, :n]).cpu().numpy()
     _check(got, orc.quantile_inverse(x_cpu.numpy()[:, :n], z["quantiles"], z["references"], True), z["quantiles"])
+
+
+# ------------------------------------------------------------------------------------------------ the other two normalisers
+def _affine():
+    z = np.load(os.path.join(GOLD, "affine.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_oracle_affine_inverse_matches_fitted_scalers():
+    z = _affine()
+    assert np.array_equal(orc.affine_inverse(z["standard_x"], "standard", z["standard_scale"], z["standard_mean"]), z["standard_want"])
+    assert np.array_equal(orc.affine_inverse(z["minmax_x"], "minmax", z["minmax_min"], z["minmax_scale"]), z["minmax_want"])
+    with pytest.raises(ValueError):
+        orc.affine_inverse(z["minmax_x"], "robust", z["minmax_min"], z["minmax_scale"])
+
+
+class _Standard:
+    def __init__(self, z):
+        self.scale_, self.mean_, self.with_std, self.with_mean = z["standard_scale"], z["standard_mean"], True, True
+
+
+class _MinMax:
+    def __init__(self, z):
+        self.min_, self.scale_ = z["minmax_min"], z["minmax_scale"]
+
+
+@pytest.mark.gpu
+def test_gpu_affine_inverse_bit_exact():
+    """StandardScaler / MinMaxScaler inverse on the device: two fp64 roundings in scikit-learn's order -> bit-exact."""
+    import midst_toolkit_amd as mtk
+
+    z = _affine()
+    dev = torch.device("cuda:0")
+    for tag, fitted in (("standard", _Standard(z)), ("minmax", _MinMax(z))):
+        inv = mtk.inverse_transform_for(fitted, dev)
+        assert isinstance(inv, mtk.AffineInverse)
+        got = inv.inverse_transform(torch.from_numpy(z[f"{tag}_x"]).to(dev)).cpu().numpy()
+        assert np.array_equal(got, z[f"{tag}_want"]), tag
+        assert inv.inverse_transform(torch.empty((0, got.shape[1]), dtype=torch.float64, device=dev)).shape == (0, got.shape[1])
+    assert isinstance(mtk.inverse_transform_for(_Fitted(load("small")), dev), mtk.QuantileInverse)
+    with pytest.raises(ValueError):
+        mtk.AffineInverse(object(), dev)

@@ -461,7 +461,33 @@ def gen_kl(tag):
     print(f"kl {tag}: rows dtype float64, mixed_loss gauss mean {float(g_mean):.6g} ({g_mean.dtype})")
 
 
+def gen_affine():
+    """The reference's STANDARD and MINMAX normalisers (common/dataset_transformations.py:66-69) fitted on its single-table
+    asset; inputs in the normalised space and the fitted objects' inverse_transform of them."""
+    import pandas as pd
+    from midst_toolkit.common.dataset_transformations import normalize
+    from midst_toolkit.common.enumerations import Normalization
+
+    g = np.random.default_rng(78)
+    train = pd.read_csv("/root/reference/tests/integration/assets/single_table/train.csv").select_dtypes("number").to_numpy(dtype=np.float64)
+    out = {}
+    for tag, norm in (("standard", Normalization.STANDARD), ("minmax", Normalization.MINMAX)):
+        _, sc = normalize({"train": train}, norm, seed=0)
+        x = g.normal(0, 1.5, (512, train.shape[1])) if tag == "standard" else g.random((512, train.shape[1])) * 1.4 - 0.2
+        out[f"{tag}_x"] = x
+        out[f"{tag}_want"] = sc.inverse_transform(x.copy())
+        if tag == "standard":
+            out["standard_scale"], out["standard_mean"] = sc.scale_, sc.mean_
+        else:
+            out["minmax_min"], out["minmax_scale"] = sc.min_, sc.scale_
+    np.savez_compressed(os.path.join(OUT, "affine.npz"), **out)
+    print("affine: standard + minmax,", train.shape[1], "columns")
+
+
 def main():
+    if "--affine-only" in sys.argv:
+        gen_affine()
+        return
     if "--kl-only" in sys.argv:
         for tag in ("A_numeric", "B_ragged", "M_mixed"):
             gen_kl(tag)
@@ -484,6 +510,7 @@ def main():
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         gen_loader()
         gen_quantile()
+        gen_affine()
         for tag in ("A_numeric", "B_ragged", "M_mixed"):
             gen_kl(tag)
         gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
