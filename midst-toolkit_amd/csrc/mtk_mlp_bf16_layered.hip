@@ -41,9 +41,9 @@ constexpr int NT = 2, WN = NT * 32;  // a wave's tile: 128 records (4 MFMA tiles
 // no MFMAs spent on 128 padding columns, and still one tile per 256 records, so a 65,536-row pass fills all 256 CUs.
 template <int WR, int MW> struct Geo {
     static constexpr int WC = 8 / WR, BM = WR * MW * 32, BN = WC * WN;
-    static constexpr int kTileX = BM * BK * 2, kTileW = BN * BK * 2, kBuf = kTileX + kTileW;
+    static constexpr int kTileX = BM * BK * 2, kTileW = BN * BK * 2;  // bytes of a record / weight tile of one k-block
     static constexpr int XPW = BM / 64, WPW = BN / 64, OPW = XPW + WPW;  // 8-row, 1 KiB DMA pieces per wave and k-block: records, weights
-    };
+};
 // THREE record buffers and two weight buffers (96 + 64 KB = 160 KB for the hidden layers): records are the long-latency
 // operand (HBM / Infinity Cache, ~2 us), weights hit the L2, so the record stream runs one k-block further ahead.
 template <int WR, int MW> constexpr size_t lds_bytes() { return 3 * Geo<WR, MW>::kTileX + 2 * Geo<WR, MW>::kTileW; }
