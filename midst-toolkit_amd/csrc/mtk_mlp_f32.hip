@@ -55,27 +55,43 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    for (int k0 = 0; k0 < g.Kpad; k0 += BK) {
+    // Operand tiles move global -> registers -> LDS, the registers one k-block ahead of the MFMAs (native vectors in
+    // named variables: a HIP float4 array here ends up in a stack slot, see mtk_train.hip).
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3;
+    auto fetch_q = [&](int k0, int q, v4f& xv, v4f& wv) {
+        const int idx = tid + 256 * q, r = idx >> 3, c = (idx & 7) * 4;
+        if (XGEN) {
+            const int64_t row = m0 + r;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + 256 * q, r = idx >> 3, c = (idx & 7) * 4;
-            float4 v;
-            if (XGEN) {
-                const int64_t row = m0 + r;
-                float e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kk = k0 + c + j;
-                    e[j] = (row < g.M && kk < g.K) ? g.X[row * g.x_rs + (int64_t)kk * g.x_cs] : 0.0f;
-                }
-                v = make_float4(e[0], e[1], e[2], e[3]);
-            } else {
-                v = *reinterpret_cast<const float4*>(g.X + (m0 + r) * g.x_rs + k0 + c);
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k0 + c + j;
+                xv[j] = (row < g.M && kk < g.K) ? g.X[row * g.x_rs + (int64_t)kk * g.x_cs] : 0.0f;
             }
-            *reinterpret_cast<float4*>(&As[r][c]) = v;
-            *reinterpret_cast<float4*>(&Bs[r][c]) = *reinterpret_cast<const float4*>(g.W + (int64_t)(n0 + r) * g.ldw + k0 + c);
+        } else {
+            xv = *reinterpret_cast<const v4f*>(g.X + (m0 + r) * g.x_rs + k0 + c);
         }
+        wv = *reinterpret_cast<const v4f*>(g.W + (int64_t)(n0 + r) * g.ldw + k0 + c);
+    };
+    auto fetch = [&](int k0) {
+        fetch_q(k0, 0, xa0, wb0);
+        fetch_q(k0, 1, xa1, wb1);
+        fetch_q(k0, 2, xa2, wb2);
+        fetch_q(k0, 3, xa3, wb3);
+    };
+    auto stash_q = [&](int q, const v4f& xv, const v4f& wv) {
+        const int idx = tid + 256 * q, r = idx >> 3, c = (idx & 7) * 4;
+        *reinterpret_cast<v4f*>(&As[r][c]) = xv;
+        *reinterpret_cast<v4f*>(&Bs[r][c]) = wv;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.Kpad; k0 += BK) {
+        stash_q(0, xa0, wb0);
+        stash_q(1, xa1, wb1);
+        stash_q(2, xa2, wb2);
+        stash_q(3, xa3, wb3);
         __syncthreads();
+        if (k0 + BK < g.Kpad) fetch(k0 + BK);  // next k-block's loads fly while this one is multiplied
         // lane (li, hh) owns k in [16 hh, 16 hh + 16) of this K block for both operands
         float a[2][16], b[2][16];
 #pragma unroll
