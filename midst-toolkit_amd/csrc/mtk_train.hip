@@ -39,6 +39,8 @@ struct G2 {
     const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed where mask <= 0
     int relu;
     int atomic;                    // accumulate with fp32 atomic add (split-K)
+    float* rowsum;                 // optional [M]: += sum_k A[m][k] (the bias gradient rides in the wgrad GEMM: the waves of
+                                   // column tile 0 sum the A fragments they hold anyway; atomics, like C under split-K)
 };
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
@@ -137,6 +139,11 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
+    const bool sum_rows = g.rowsum != nullptr && blockIdx.y == 0 && wc == 0;  // wave-uniform
+    float rs[WT];
+#pragma unroll
+    for (int a = 0; a < WT; ++a) rs[a] = 0.0f;
+
     TileMover<AT, T> ma;
     TileMover<BT, T> mb;
     ma.load(g.A, g.lda, m0, kbeg, tid);
@@ -154,6 +161,15 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
         for (int mt = 0; mt < WT; ++mt) TileMover<AT, T>::frag(As, wr * 32 * WT + mt * 32 + li, hh, a[mt]);
 #pragma unroll
         for (int nt = 0; nt < WT; ++nt) TileMover<BT, T>::frag(Bs, wc * 32 * WT + nt * 32 + li, hh, b[nt]);
+        if (sum_rows) {
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt) {
+                float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 16; s += 2) { t0 += a[mt][s]; t1 += a[mt][s + 1]; }
+                rs[mt] += t0 + t1;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
@@ -162,6 +178,13 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 for (int nt = 0; nt < WT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
         __syncthreads();
+    }
+    if (sum_rows) {  // lanes l and l + 32 hold the two k-halves of row (lane & 31)
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt) {
+            const float tot = rs[mt] + __shfl_xor(rs[mt], 32);
+            if (hh == 0) unsafeAtomicAdd(&g.rowsum[m0 + wr * 32 * WT + mt * 32 + li], tot);
+        }
     }
 
     // C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -539,8 +562,8 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = dy; g.lda = l.out_pad; g.B = tr.act[i]; g.ldb = l.in_pad;
         g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
+        g.rowsum = grads + r.b_off;  // db[o] = sum_m dy[m][o]
         if ((rc = launch<true, true>(g, s))) return rc;
-        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 256), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
         G2 d{};
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
@@ -557,8 +580,8 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
         g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
+        g.rowsum = grads + r.b_off;
         if ((rc = launch<true, false>(g, s))) return rc;
-        hipLaunchKernelGGL(k_colsum_rm, dim3((l.out_pad + 255) / 256, 256), dim3(256), 0, s, dy, (int64_t)l.out_pad, Mpad, l.out_pad, grads + r.b_off);
         hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld);
     }
     {   // time-embedding MLP over the T-row table
