@@ -66,7 +66,7 @@ def big_batch(c, B, seed=5):
 
 
 @pytest.mark.parametrize("tag,B,layers", [("B_ragged", 24, None), ("A_numeric", 24, None), ("B_ragged", 1000, [256, 128, 256]),
-                                          ("M", 4096, [512] * 4)])
+                                          ("M", 4096, [512] * 4), ("M", 16384, [1024, 1024])])  # the last: 128 x 128 tiles in wgrad too
 def test_gradients_match_autograd(tag, B, layers):
     if tag == "M":
         c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=layers)
