@@ -290,12 +290,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int li_e = lane_e & 31, hh_e = lane_e >> 5;
+        int trs[MW];  // first layer: the timesteps of the lane's MW records, requested together (one round trip, not MW)
+        if (EMB) {
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt) {
+                const int64_t row = m0 + (wr * MW + mt) * 32 + li_e;
+                trs[mt] = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
             const int64_t row = m0 + (wr * MW + mt) * 32 + li_e;
             float4 eq[NT * 4];  // time-embedding row of the record (first layer only): all eight loads in flight together
             if (EMB) {
-                const int tr = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
+                const int tr = trs[mt];
 #pragma unroll
                 for (int i = 0; i < NT * 4; ++i) {
                     const int n = n0 + wc * WN + (i >> 2) * 32 + 8 * (i & 3) + 4 * hh_e;
