@@ -1,4 +1,4 @@
-"""Layered bf16 denoiser alone (shape M, 4 x hidden): python benchmarks/bench_layered.py [--rows N] [--hidden H].
+"""Layered denoiser alone (shape M, 4 x hidden; --precision bf16 | bf16x3 | fp32; a 4 x 512 bf16 run takes the fused kernel): python benchmarks/bench_layered.py [--rows N] [--hidden H].
 A/B builds: MTK_LIB_PATH=<other libmtk_hip.so>; chunking: MTK_LAYERED_CHUNK=<rows>."""
 import argparse
 import json
@@ -17,17 +17,19 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20)
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--D", type=int, default=120)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    B, D = a.rows, 120
+    B, D = a.rows, a.D
     torch.manual_seed(0)
     net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([a.hidden] * 4, 0.0)).to(dev)
-    net.precision = "bf16"
+    net.precision = a.precision
     eng = net.engine(dev)
     x_in = torch.randn((D, B), device=dev)
     out = torch.empty((D, B), device=dev)
     t = torch.randint(0, 1000, (B,), device=dev)
-    fn = lambda: eng.mlp_forward(x_in, t, out=out, precision="bf16", x_strides=(1, B), out_strides=(1, B), B=B)  # noqa: E731
+    fn = lambda: eng.mlp_forward(x_in, t, out=out, precision=a.precision, x_strides=(1, B), out_strides=(1, B), B=B)  # noqa: E731
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -40,7 +42,7 @@ def main():
     secs = float(np.median([s.elapsed_time(e) for s, e in ev])) * 1e-3
     fl = 2 * (D * 128 + 128 * a.hidden + 3 * a.hidden ** 2 + a.hidden * D)
     print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("MTK_LIB_PATH", "libmtk_hip.so")), "chunk": os.environ.get("MTK_LAYERED_CHUNK", "auto"),
-                      "rows": B, "hidden": a.hidden, "ms": secs * 1e3, "TFLOP/s": B * fl / secs / 1e12, "frac_of_peak": B * fl / secs / 2.5e15}), flush=True)
+                      "rows": B, "hidden": a.hidden, "precision": a.precision, "ms": secs * 1e3, "TFLOP/s": B * fl / secs / 1e12, "frac_of_peak": B * fl / secs / (157.3e12 if a.precision == "fp32" else 2.5e15)}), flush=True)
 
 
 if __name__ == "__main__":

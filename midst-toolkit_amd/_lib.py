@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTK_LIB_PATH") or os.path.join(_HERE, "libmtk_hip.so")  # override: A/B builds of the same ABI
 
 MTK_OK, MTK_ERR_ARG, MTK_ERR_UNSUPPORTED, MTK_ERR_HIP, MTK_ERR_STATE = 0, -1, -2, -3, -4
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 NTAB = 15
 TABLE_ORDER = [
     "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_alpha", "log_1_min_alpha", "log_cumprod_alpha",

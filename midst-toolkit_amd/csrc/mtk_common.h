@@ -97,7 +97,8 @@ struct mtk_ctx {
     float* d_embb = nullptr;      // [T][emb_ld] time-embedding table + proj bias (fused kernel)
     bool fused_ok = false;
     // layered bf16 path (mtk_mlp_bf16_layered.hip): bf16 weight images per layer + activation ping-pong
-    std::vector<void*> wb16;
+    std::vector<void*> wb16;    // plain bf16 weight images (shapes the fused kernel does not cover)
+    std::vector<void*> wb16x;   // split (hi | lo) bf16 weight images, MTK_PREC_BF16X3 (every shape)
     std::vector<float*> bb16;
     void* ws16[2] = {nullptr, nullptr};
     size_t ws16_elems = 0;
@@ -120,7 +121,15 @@ struct mtk_ctx {
 #define MTK_LOG_TINY (-0x1.144f6ap+6f) /* fp32 log(1e-30f) = -69.07755, DU:227 */
 #define MTK_TINY (0x1.4484cp-100f)     /* 1e-30f */
 
+// Per-row timesteps come from device memory the host never sees.  Every kernel clamps them into the schedule tables
+// for addressing (mtk_tclamp) and the entry point then overwrites the outputs of rows whose timestep was outside
+// [0, T) with NaN (mtk_poison_bad_t, mtk_diffusion.hip): an out-of-range timestep is loud, never an out-of-bounds read.
+// The reference's sinusoid embedding accepts any t; here the embedding is a [T] table.
+int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0, int64_t cs0, int n0, float* p1, int64_t rs1,
+                     int64_t cs1, int n1, double* p2, hipStream_t s);
+
 #ifdef __HIPCC__
+__device__ __forceinline__ int mtk_tclamp(int64_t tv, int T) { return tv < 0 ? 0 : (tv >= T ? T - 1 : (int)tv); }
 // Philox-4x32-10 (Salmon et al., SC'11).  Counter = (row_lo, row_hi, group, stream), key = seed.
 __device__ __forceinline__ uint4 mtk_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint64_t seed) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);

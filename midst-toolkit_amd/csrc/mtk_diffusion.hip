@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
-        const int t = (int)a.t[row];
+        const int t = mtk_tclamp(a.t[row], a.d.T);
         const SchedRow sr = s.rows[t];
         const float* xr = a.x0 + row * a.x0_ld;
         float* xo = a.x_in + row * a.xi_rs;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
     const SchedRow srT = s.rows[T - 1];
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
-        const int t = (int)a.t[row];
+        const int t = mtk_tclamp(a.t[row], a.d.T);
         const float* mo = a.mo + row * a.mo_rs;
         if (a.loss_gauss && Nn > 0) {  // mean_d (eps - eps_hat)^2
             PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
             xr = a.x0 + row * a.x0_ld;
         }
         if (row >= a.B) continue;
-        const int t = (int)a.t[row];
+        const int t = mtk_tclamp(a.t[row], a.d.T);
         float* xo = a.x_in + row * a.xi_rs;
         // first group of inputs in flight before anything is consumed
         float xv[kGroup], ev[kGroup];
@@ -744,7 +744,7 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
             xr = a.x0 ? a.x0 + row * a.x0_ld : nullptr;
         }
         if (row >= a.B) continue;
-        const int t = (int)a.t[row];
+        const int t = mtk_tclamp(a.t[row], a.d.T);
         const float* mo = a.mo + row * a.mo_rs;
         const bool multi = a.loss_multi && C > 0;
         // the first categorical block's inputs go out before the Gaussian part is consumed
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
         const int64_t row = base + lane;
         float accg = 0.0f, accm = 0.0f;
         if (row < a.B) {
-            const int t = (int)a.t[row];
+            const int t = mtk_tclamp(a.t[row], a.d.T);
             const float* mo = a.out + row;
             float* go = a.dout + row;
             PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
@@ -1172,7 +1172,7 @@ __device__ __forceinline__ double approx_normal_cdf(double v) {  // DU:48-59
 __global__ __launch_bounds__(kBlock) void k_gauss_kl_rows(KlArgs a) {
     const double inv_ln2 = 1.0 / 0.69314718055994530942;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
-        const int t = (int)a.t[row];
+        const int t = mtk_tclamp(a.t[row], a.T);
         const SchedRow sr = a.rows[t];
         const double* tb = a.tab + (size_t)t * 4;
         const float c1 = (float)tb[0], c2 = (float)tb[1], lv1 = (float)tb[2];
@@ -1212,6 +1212,24 @@ __global__ __launch_bounds__(kBlock) void k_gauss_kl_rows(KlArgs a) {
     }
 }
 
+// rows whose timestep lies outside [0, T): every output element of the row becomes NaN (see mtk_tclamp)
+struct PoisonArgs {
+    const int64_t* t; int64_t B; int T;
+    float* p0; int64_t rs0, cs0; int n0;
+    float* p1; int64_t rs1, cs1; int n1;
+    double* p2;
+};
+__global__ __launch_bounds__(kBlock) void k_poison_bad_t(PoisonArgs a) {
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        const int64_t tv = a.t[row];
+        if (tv >= 0 && tv < a.T) continue;
+        const float qn = __builtin_nanf("");
+        if (a.p0) for (int j = 0; j < a.n0; ++j) a.p0[row * a.rs0 + j * a.cs0] = qn;
+        if (a.p1) for (int j = 0; j < a.n1; ++j) a.p1[row * a.rs1 + j * a.cs1] = qn;
+        if (a.p2) a.p2[row] = __builtin_nan("");
+    }
+}
+
 int max_levels(const mtk_ctx* c) {  // widest categorical block of the table
     int m = 0;
     for (int32_t k : c->K) m = k > m ? k : m;
@@ -1230,6 +1248,15 @@ size_t lds_bytes(const mtk_ctx* c, bool rows) {
 }
 
 }  // namespace
+
+int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0, int64_t cs0, int n0, float* p1, int64_t rs1,
+                     int64_t cs1, int n1, double* p2, hipStream_t s) {
+    if (!t || B <= 0 || (!p0 && !p1 && !p2)) return MTK_OK;
+    PoisonArgs a{t, B, T, p0, rs0, cs0, n0, p1, rs1, cs1, n1, p2};
+    hipLaunchKernelGGL(k_poison_bad_t, dim3(grid_for(B)), dim3(kBlock), 0, s, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
 
 // internal (mtk_train.hip): per-record losses and d(mean loss)/d(out); out / dout column-major [D][ld]
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
@@ -1263,12 +1290,12 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
         hipLaunchKernelGGL((k_q_sample_fast<false, true>), dim3(grid_for(B)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
-        return MTK_OK;
+        return mtk_poison_bad_t(t, B, ctx->T, x_in, xi_rs, xi_cs, ctx->D, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
     }
     auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true, false> : k_q_sample_fast<false, false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
-    return MTK_OK;
+    return mtk_poison_bad_t(t, B, ctx->T, x_in, xi_rs, xi_cs, ctx->D, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, int64_t mo_rs, int64_t mo_cs, const float* x0,
@@ -1289,14 +1316,14 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
         hipLaunchKernelGGL(ks, dim3(grid_for(B)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
-        return MTK_OK;
+        return mtk_poison_bad_t(t, B, ctx->T, loss_multi, 1, 0, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);  // the MSE term does not depend on t
     }
     auto kf = small ? (lds ? k_loss_rows_fast_small<true, false> : k_loss_rows_fast_small<false, false>)
                     : (lds ? k_loss_rows_fast<true, false> : k_loss_rows_fast<false, false>);
     auto k = ctx->fast_math ? kf : (lds ? k_loss_rows<true> : k_loss_rows<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
-    return MTK_OK;
+    return mtk_poison_bad_t(t, B, ctx->T, ctx->C > 0 ? loss_multi : nullptr, 1, 0, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);  // the MSE term does not depend on t
 }
 
 extern "C" int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int first_step, const float* model_out, int64_t mo_rs,
@@ -1403,7 +1430,7 @@ extern "C" int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out
     KlArgs a{B, ctx->Nn, ctx->T, ctx->d_rows, ctx->d_kl, model_out, mo_rs, mo_cs, x0, x0_ld, x_t, xt_rs, xt_cs, t, loss};
     hipLaunchKernelGGL(k_gauss_kl_rows, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
-    return MTK_OK;
+    return mtk_poison_bad_t(t, B, ctx->T, nullptr, 0, 0, 0, nullptr, 0, 0, 0, loss, (hipStream_t)stream);
 }
 
 extern "C" int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, double* sample,

@@ -52,6 +52,7 @@ struct FusedArgs {
     // mode 0
     const float* x; int64_t x_rs, x_cs;
     const int64_t* tvec; int t_scalar;
+    int T;  // rows of embb: per-row timesteps are clamped into it (mtk_tclamp); the host poisons such rows afterwards
     float* out; int64_t o_rs, o_cs;
     // mode 1
     int64_t BP; int P; int64_t x_ld;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     // ---- MODE 0: per-tile inputs are requested one tile ahead (a single wave per SIMD has nothing else to hide a
     // ---- global-memory round trip behind): the timestep first, then the record and the emb[t] + bias rows
     auto request_t = [&](const Where& w) -> int {
-        return a.tvec ? (w.valid ? (int)a.tvec[w.row] : 0) : a.t_scalar;
+        return a.tvec ? (w.valid ? mtk_tclamp(a.tvec[w.row], a.T) : 0) : a.t_scalar;
     };
     float raw[MODE == 0 ? KS0 * 8 : 1];
     auto request_x = [&](const Where& w) {
@@ -732,9 +733,10 @@ int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64
     a.rows = B;
     a.mode = 0;
     a.x = x; a.x_rs = x_rs; a.x_cs = x_cs;
-    a.tvec = t; a.t_scalar = t_scalar;
+    a.tvec = t; a.t_scalar = t_scalar; a.T = c->T;
     a.out = out; a.o_rs = o_rs; a.o_cs = o_cs;
-    return run(c, a, s);
+    const int rc = run(c, a, s);
+    return rc ? rc : mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
 }
 
 // Returns MTK_ERR_UNSUPPORTED (without setting up anything) when the staged-record layout cannot hold this shape:

@@ -55,12 +55,15 @@ struct GemmB {
     int nb_n;        // column tiles (Npad / BN)
     int Kpad;        // multiple of BK: extent of the bf16 operands
     const uint16_t* X; int64_t x_ld;   // bf16 [Mpad][x_ld]
-    const uint16_t* W;                 // bf16 [Npad256][Kpad], zero padded
+    int64_t x_lo;                      // split mode: column offset of the low halves inside a record row (>= Kpad)
+    const uint16_t* W; int64_t w_ld;   // bf16 [Npad256][w_ld], zero padded (w_ld = Kpad; split mode: 2 Kpad, hi | lo)
     const float* bias;                 // [Npad256], zero padded
     const float* emb; int emb_ld; const int64_t* tvec; int t_scalar;  // optional time-embedding gather (first layer)
+    int T;           // rows of emb: per-row timesteps are clamped into it; the host poisons such rows afterwards (mtk_tclamp)
     int relu;
     // output: bf16 row-major [Mpad][y_rs] (OF32 = false) or fp32 with generic strides, bounds-checked (OF32 = true)
     void* Y; int64_t y_rs, y_cs;
+    int64_t y_lo;    // SPLIT, bf16 output: column offset of the low halves inside an output row
     unsigned long long* stamps;  // DIAG_STAMPS builds only
 };
 
@@ -73,7 +76,13 @@ extern __shared__ __attribute__((aligned(16))) uint16_t gb_smem[];
 // EMB: the first layer's epilogue adds the record's time-embedding row (vector loads).  It is a template parameter, not
 // a run-time branch: the compiler put the loads' `s_waitcnt vmcnt(0)` at the join of the branch, where every layer
 // then waited, once per 32 rows, for its previous stores and the DMA in flight (~1 us each).
-template <bool OF32, int WR, int MW, bool EMB>
+// SPLIT (MTK_PREC_BF16X3): every fp32 value v travels as two bf16 numbers, hi = bf16(v) and lo = bf16(v - hi) (v = hi + lo
+// to ~2^-17 relative), stored as the two halves [hi | lo] of a row of 2 Kpad elements, for activations and weights
+// alike.  x.w ~ xh.wh + xl.wh + xh.wl (the dropped xl.wl term is ~2^-16 of the product): the same k-loop walks 3 nkb
+// k-blocks - phase 0 reads (xh, wh), phase 1 (xl, wh), phase 2 (xh, wl) - into the same fp32 accumulators, so the
+// arithmetic is three bf16 MFMAs per product with fp32 accumulation and nothing else changes: same tiles, same DMA
+// stream, same barriers.  The epilogue splits its fp32 result again and stores both halves.
+template <bool OF32, int WR, int MW, bool EMB, bool SPLIT>
 __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     typedef Geo<WR, MW> G;
     constexpr int kTileX = G::kTileX, kTileW = G::kTileW, kWBase = 3 * G::kTileX;
@@ -86,7 +95,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, wstride = gridDim.x >> 3;
     const int64_t slots = ((g.MT - xcd + 7) / 8) * g.nb_n;  // this XCD's tiles
     if (wq >= slots) return;
-    const int nkb = g.Kpad / BK;
+    const int nkb1 = g.Kpad / BK;               // k-blocks of one operand half
+    const int nkb = SPLIT ? 3 * nkb1 : nkb1;    // k-blocks a tile consumes
+    // first column (element offset inside a row) that k-block kb of a tile reads from the record / weight matrix
+    auto xcol = [&](int kb) -> int64_t {
+        if (!SPLIT) return (int64_t)kb * BK;
+        return kb < nkb1 ? (int64_t)kb * BK : (kb < 2 * nkb1 ? g.x_lo + (int64_t)(kb - nkb1) * BK : (int64_t)(kb - 2 * nkb1) * BK);
+    };
+    auto wcol = [&](int kb) -> int64_t { return (int64_t)((SPLIT && kb >= nkb1) ? kb - nkb1 : kb) * BK; };  // weights: [hi | lo], lo at Kpad
 
     const int wv = __builtin_amdgcn_readfirstlane(wid);
     const int lr = lane >> 3;
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     for (int par = 0; par < 2; ++par) {
         const int lc = (lane & 7) ^ ((lr >> 1) | (par << 2));
         voff_x[par] = (unsigned)(lr * g.x_ld * 2 + lc * 16);
-        voff_w[par] = (unsigned)(lr * g.Kpad * 2 + lc * 16);
+        voff_w[par] = (unsigned)(lr * g.w_ld * 2 + lc * 16);
     }
     // Operand tiles (256 rows x 64 bf16 = one 128-byte line per row, 32 KB) go L2 -> LDS by LDS-DMA, no registers
     // involved: one wave-instruction moves 8 full lines (64 lanes x 16 B) into 1 KiB of LDS, 4 + 4 of them per wave and
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     struct Cursor { int64_t slot; int kb; int buf; const unsigned char* base; };
     Cursor cx{wq, 0, 0, nullptr}, cw{wq, 0, 0, nullptr};
     auto x_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.X + ((slot / g.nb_n) * 8 + xcd) * G::BM * g.x_ld); };
-    auto w_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.W + (int64_t)((int)(slot % g.nb_n) * G::BN) * g.Kpad); };
+    auto w_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.W + (int64_t)((int)(slot % g.nb_n) * G::BN) * g.w_ld); };
     auto dma = [&](const unsigned char* gp, unsigned voff, unsigned dst) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -119,12 +135,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     auto x_op = [&](int j) {  // piece j of this wave's XPW of the record block at the cursor
         if (cx.slot >= slots) return;
         const int chunk = wv * G::XPW + j;
-        dma(cx.base + (int64_t)chunk * 8 * g.x_ld * 2 + (int64_t)cx.kb * BK * 2, voff_x[chunk & 1], (unsigned)(cx.buf * kTileX + chunk * 1024));
+        dma(cx.base + (int64_t)chunk * 8 * g.x_ld * 2 + xcol(cx.kb) * 2, voff_x[chunk & 1], (unsigned)(cx.buf * kTileX + chunk * 1024));
     };
     auto w_op = [&](int j) {
         if (cw.slot >= slots) return;
         const int chunk = wv * G::WPW + j;
-        dma(cw.base + (int64_t)chunk * 8 * g.Kpad * 2 + (int64_t)cw.kb * BK * 2, voff_w[chunk & 1], (unsigned)(kWBase + cw.buf * kTileW + chunk * 1024));
+        dma(cw.base + (int64_t)chunk * 8 * g.w_ld * 2 + wcol(cw.kb) * 2, voff_w[chunk & 1], (unsigned)(kWBase + cw.buf * kTileW + chunk * 1024));
     };
     auto x_advance = [&]() {
         if (cx.slot >= slots) return;
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
 #pragma unroll
             for (int mt = 0; mt < MW; ++mt) {
                 const int64_t row = m0 + (wr * MW + mt) * 32 + li_e;
-                trs[mt] = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
+                trs[mt] = (g.tvec && row < g.M) ? mtk_tclamp(g.tvec[row], g.T) : (g.tvec ? 0 : g.t_scalar);
             }
         }
 #pragma unroll
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 unsigned pk[4][2];  // [q]: the lane's 4 features of group q as two packed bf16 pairs
+                unsigned pl[SPLIT ? 4 : 1][2];  // SPLIT: their low halves
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int nl = nt * 32 + 8 * q + 4 * hh_e;  // feature inside the wave's 64
@@ -337,6 +354,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                         const __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                         pk[q][0] = reinterpret_cast<const unsigned*>(e)[0];
                         pk[q][1] = reinterpret_cast<const unsigned*>(e)[1];
+                        if (SPLIT) {  // low halves: what the bf16 rounding of v left behind, itself rounded to bf16
+                            const __bf16 l[4] = {(__bf16)(v[0] - (float)e[0]), (__bf16)(v[1] - (float)e[1]), (__bf16)(v[2] - (float)e[2]),
+                                                 (__bf16)(v[3] - (float)e[3])};
+                            pl[q][0] = reinterpret_cast<const unsigned*>(l)[0];
+                            pl[q][1] = reinterpret_cast<const unsigned*>(l)[1];
+                        }
                     }
                 }
                 if (!OF32) {
@@ -351,6 +374,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][0], pk[2 * p2][0], false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][1], pk[2 * p2][1], false, false);
                         *reinterpret_cast<uint4*>(yb + 8 * (2 * p2 + (hh_e ? 0 : 1))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        if (SPLIT) {  // the low halves go to the second half of the output row (y_lo = column offset of it)
+                            const auto l0 = __builtin_amdgcn_permlane32_swap(pl[2 * p2 + 1][0], pl[2 * p2][0], false, false);
+                            const auto l1 = __builtin_amdgcn_permlane32_swap(pl[2 * p2 + 1][1], pl[2 * p2][1], false, false);
+                            *reinterpret_cast<uint4*>(yb + g.y_lo + 8 * (2 * p2 + (hh_e ? 0 : 1))) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+                        }
                     }
                 }
             }
@@ -383,6 +411,18 @@ __global__ void k_to_bf16_pad(uint16_t* dst, int rows_pad, int cols_pad, const f
         dst[i] = *reinterpret_cast<const uint16_t*>(&b);
     }
 }
+// split image: [rows_pad][2 cols_pad], hi = bf16(w) in the first half of a row, lo = bf16(w - hi) in the second
+__global__ void k_to_bf16_split_pad(uint16_t* dst, int rows_pad, int cols_pad, const float* src, int src_ld, int rows, int cols) {
+    const int64_t n = (int64_t)rows_pad * cols_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+        const float v = (r < rows && c < cols) ? src[(int64_t)r * src_ld + c] : 0.0f;
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        dst[(int64_t)r * 2 * cols_pad + c] = *reinterpret_cast<const uint16_t*>(&h);
+        dst[(int64_t)r * 2 * cols_pad + cols_pad + c] = *reinterpret_cast<const uint16_t*>(&l);
+    }
+}
 __global__ void k_pad_f32(float* dst, int n_pad, const float* src, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) dst[i] = i < n ? src[i] : 0.0f;
 }
@@ -390,8 +430,11 @@ __global__ void k_pad_f32(float* dst, int n_pad, const float* src, int n) {
 // converts 64 rows x 128 columns through LDS: it reads along whichever direction of the source is contiguous (lanes
 // over rows for the column-major intermediates, over columns for the row-major tensors of the drop-in API) and writes
 // whole 256-byte rows of the destination (a thread per 8 columns wrote 16-byte pieces 256 B apart: 2 TB/s).
+// SPLIT: the destination row is [hi (ld) | lo (ld)], lo = bf16(x - hi).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_x_to_bf16(uint16_t* dst, int ld, const float* x, int64_t x_rs, int64_t x_cs, int64_t M, int D) {
     __shared__ uint32_t tile[64 * 65];  // [row][column pair], odd row stride: conflict-free both ways
+    __shared__ uint32_t tile_lo[SPLIT ? 64 * 65 : 1];
     const int t = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int col0 = blockIdx.y * 128;
@@ -405,16 +448,26 @@ __global__ __launch_bounds__(256) void k_x_to_bf16(uint16_t* dst, int ld, const 
         const bool ok0 = row < M && c < D, ok1 = row < M && c + 1 < D;
         const float v0 = x[(ok0 ? row : 0) * x_rs + (int64_t)(ok0 ? c : 0) * x_cs];
         const float v1 = x[(ok1 ? row : 0) * x_rs + (int64_t)(ok1 ? c + 1 : 0) * x_cs];
-        const __bf16 e[2] = {(__bf16)(ok0 ? v0 : 0.0f), (__bf16)(ok1 ? v1 : 0.0f)};
+        const float f0 = ok0 ? v0 : 0.0f, f1 = ok1 ? v1 : 0.0f;
+        const __bf16 e[2] = {(__bf16)f0, (__bf16)f1};
         tile[r * 65 + cp] = *reinterpret_cast<const uint32_t*>(e);
+        if (SPLIT) {
+            const __bf16 l[2] = {(__bf16)(f0 - (float)e[0]), (__bf16)(f1 - (float)e[1])};
+            tile_lo[r * 65 + cp] = *reinterpret_cast<const uint32_t*>(l);
+        }
     }
     __syncthreads();
+    const int64_t dld = SPLIT ? 2 * (int64_t)ld : ld;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pc = t + 256 * i, r = pc >> 4, c8 = pc & 15;
         if (col0 + c8 * 8 < ld) {
             const uint32_t* q = tile + r * 65 + c8 * 4;
-            *reinterpret_cast<uint4*>(dst + (row0 + r) * ld + col0 + c8 * 8) = make_uint4(q[0], q[1], q[2], q[3]);
+            *reinterpret_cast<uint4*>(dst + (row0 + r) * dld + col0 + c8 * 8) = make_uint4(q[0], q[1], q[2], q[3]);
+            if (SPLIT) {
+                const uint32_t* ql = tile_lo + r * 65 + c8 * 4;
+                *reinterpret_cast<uint4*>(dst + (row0 + r) * dld + ld + col0 + c8 * 8) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+            }
         }
     }
 }
@@ -430,13 +483,13 @@ int n_cus_layered(int device) {
     return n;
 }
 
-template <bool OF32, int WR, int MW, bool EMB = false>
+template <bool OF32, int WR, int MW, bool EMB = false, bool SPLIT = false>
 int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     typedef Geo<WR, MW> G;
     constexpr size_t lds = lds_bytes<WR, MW>();
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32, WR, MW, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16<OF32, WR, MW, EMB, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     if (Mpad % G::BM || Npad % G::BN) MTK_FAIL(MTK_ERR_STATE, "layered bf16 GEMM: %lld x %d is not a multiple of the %d x %d tile", (long long)Mpad, Npad, G::BM, G::BN);
@@ -453,7 +506,7 @@ int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     MTK_HIP(hipMemsetAsync(d_st, 0, 128, s));
     g.stamps = d_st;
 #endif
-    hipLaunchKernelGGL((k_gemm_bf16<OF32, WR, MW, EMB>), dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, g);
+    hipLaunchKernelGGL((k_gemm_bf16<OF32, WR, MW, EMB, SPLIT>), dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, g);
     MTK_HIP(hipGetLastError());
 #ifdef DIAG_STAMPS
     MTK_HIP(hipStreamSynchronize(s));
@@ -471,6 +524,8 @@ int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
 void mtk_free_layered(mtk_ctx* c) {
     for (void* p : c->wb16) if (p) (void)hipFree(p);
     c->wb16.clear();
+    for (void* p : c->wb16x) if (p) (void)hipFree(p);
+    c->wb16x.clear();
     for (float* p : c->bb16) if (p) (void)hipFree(p);
     c->bb16.clear();
     for (int i = 0; i < 2; ++i) {
@@ -480,9 +535,10 @@ void mtk_free_layered(mtk_ctx* c) {
     c->ws16_elems = 0;
 }
 
-// bf16 weight images [round_up(out, 256)][round_up(in_pad, 64)] and fp32 biases padded alike (called when the weights are
-// set and the fused kernel does not cover the shape)
-int mtk_pack_layered(mtk_ctx* c, hipStream_t s) {
+// Weight images for the layer-by-layer bf16 GEMMs, built when the weights are set: fp32 biases padded to
+// round_up(out, 256); split images [round_up(out, 256)][2 round_up(in_pad, 64)] (hi | lo) for MTK_PREC_BF16X3, always; plain
+// bf16 images [round_up(out, 256)][round_up(in_pad, 64)] for MTK_PREC_BF16 when the fused kernel does not cover the shape.
+int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain) {
     mtk_free_layered(c);
     std::vector<const MlpLayer*> ls{&c->proj};
     for (auto& l : c->blocks) ls.push_back(&l);
@@ -491,34 +547,55 @@ int mtk_pack_layered(mtk_ctx* c, hipStream_t s) {
         const int kp = round_up(l->in_pad, BK), np = round_up(l->out_pad, BT);
         void* p = nullptr;
         float* b = nullptr;
-        MTK_HIP(hipMalloc(&p, sizeof(uint16_t) * (size_t)np * kp));
-        c->wb16.push_back(p);
+        if (plain) {
+            MTK_HIP(hipMalloc(&p, sizeof(uint16_t) * (size_t)np * kp));
+            c->wb16.push_back(p);
+            hipLaunchKernelGGL(k_to_bf16_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(p), np, kp, l->w32, l->in_pad, l->out_pad, l->in_pad);
+        }
+        void* px = nullptr;
+        MTK_HIP(hipMalloc(&px, sizeof(uint16_t) * (size_t)np * kp * 2));
+        c->wb16x.push_back(px);
+        hipLaunchKernelGGL(k_to_bf16_split_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(px), np, kp, l->w32, l->in_pad, l->out_pad, l->in_pad);
         MTK_HIP(hipMalloc(&b, sizeof(float) * (size_t)np));
         c->bb16.push_back(b);
-        hipLaunchKernelGGL(k_to_bf16_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(p), np, kp, l->w32, l->in_pad, l->out_pad, l->in_pad);
         hipLaunchKernelGGL(k_pad_f32, dim3(8), dim3(256), 0, s, b, np, l->b32, l->out_pad);
     }
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
 
-int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
-                             float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
-    if (c->wb16.size() != c->blocks.size() + 2) MTK_FAIL(MTK_ERR_STATE, "layered bf16 denoiser: weights are not packed");
-    int maxld = round_up(c->proj.in_pad, BK);  // widest bf16 activation row (input included)
+namespace {
+
+int max_ld_layered(const mtk_ctx* c) {  // widest bf16 activation row (input included)
+    int maxld = round_up(c->proj.in_pad, BK);
     if (round_up(c->proj.out_pad, BT) > maxld) maxld = round_up(c->proj.out_pad, BT);
     for (auto& l : c->blocks) maxld = round_up(l.out_pad, BT) > maxld ? round_up(l.out_pad, BT) : maxld;
-    // Rows per pass through the layer chain: a layer's input and output (2 x rows x maxld bf16) should fit the 256 MB
-    // Infinity Cache, so that what one layer writes the next reads from there and not from HBM (4x1024, 2^20 records:
-    // 8.7 ms at 131,072 rows a pass, 8.1 ms at 65,536; below 32,768 the six launches per pass dominate).
+    return maxld;
+}
+
+// Rows per pass through the layer chain: a layer's input and output (2 x rows x row bytes) should fit the 256 MB Infinity
+// Cache, so that what one layer writes the next reads from there and not from HBM (4x1024, 2^20 records: 8.7 ms at 131,072
+// rows a pass, 8.1 ms at 65,536; below 32,768 the six launches per pass dominate).
+int64_t chunk_rows(int maxld, bool split) {
     static const int64_t chunk_env = [] { const char* e = getenv("MTK_LAYERED_CHUNK"); return e ? (int64_t)atol(e) : (int64_t)0; }();
     int64_t chunk = (chunk_env + kRowPad - 1) / kRowPad * kRowPad;
     if (chunk <= 0) {
         chunk = 32768;
-        while (chunk < 262144 && 2 * chunk * (int64_t)maxld * 4 <= ((int64_t)256 << 20)) chunk *= 2;
+        while (chunk < 262144 && 2 * chunk * (int64_t)maxld * (split ? 8 : 4) <= ((int64_t)256 << 20)) chunk *= 2;
     }
+    return chunk;
+}
+
+template <bool SPLIT>
+int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar, float* out,
+                    int64_t o_rs, int64_t o_cs, hipStream_t s) {
+    const std::vector<void*>& wimg = SPLIT ? c->wb16x : c->wb16;
+    if (wimg.size() != c->blocks.size() + 2) MTK_FAIL(MTK_ERR_STATE, "layered bf16 denoiser: weights are not packed");
+    constexpr int F = SPLIT ? 2 : 1;  // bf16 numbers per activation / weight
+    const int maxld = max_ld_layered(c);
+    const int64_t chunk = chunk_rows(maxld, SPLIT);
     const int64_t need_rows = (B < chunk ? (B + kRowPad - 1) / kRowPad * kRowPad : chunk);
-    const size_t need = (size_t)need_rows * maxld;
+    const size_t need = (size_t)need_rows * maxld * F;
     if (need > c->ws16_elems) {
         MTK_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < 2; ++i) {
@@ -533,39 +610,53 @@ int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs
         const int64_t M = (B - r0 < chunk) ? B - r0 : chunk;
         const int64_t Mpad = (M + kRowPad - 1) / kRowPad * kRowPad;
         int rc;
-        // input -> bf16 [Mpad][kp0]
+        // input -> bf16 [Mpad][F kp0]
         const int kp0 = round_up(c->proj.in_pad, BK);
-        hipLaunchKernelGGL(k_x_to_bf16, dim3((unsigned)(Mpad / 64), (unsigned)((kp0 + 127) / 128)), dim3(256), 0, s, ws[0], kp0, x + r0 * x_rs, x_rs, x_cs, M, c->D);
+        hipLaunchKernelGGL(k_x_to_bf16<SPLIT>, dim3((unsigned)(Mpad / 64), (unsigned)((kp0 + 127) / 128)), dim3(256), 0, s, ws[0], kp0, x + r0 * x_rs, x_rs, x_cs, M, c->D);
         MTK_HIP(hipGetLastError());
         int cur = 0;
         GemmB g{};
         g.M = M; g.N = c->proj.out; g.Kpad = kp0;
-        g.X = ws[cur]; g.x_ld = kp0;
-        g.W = reinterpret_cast<const uint16_t*>(c->wb16[0]); g.bias = c->bb16[0];
-        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar;
+        g.X = ws[cur]; g.x_ld = (int64_t)F * kp0; g.x_lo = kp0;
+        g.W = reinterpret_cast<const uint16_t*>(wimg[0]); g.w_ld = (int64_t)F * kp0; g.bias = c->bb16[0];
+        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar; g.T = c->T;
         int ld = round_up(c->proj.out_pad, BT);
-        g.Y = ws[cur ^ 1]; g.y_rs = ld;
-        if ((rc = launch<false, 2, 4, true>(g, c->device, Mpad, ld, s))) return rc;
+        g.Y = ws[cur ^ 1]; g.y_rs = (int64_t)F * ld; g.y_lo = ld;
+        if ((rc = launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s))) return rc;
         cur ^= 1;
         for (size_t i = 0; i < c->blocks.size(); ++i) {
             const MlpLayer& l = c->blocks[i];
             GemmB h{};
             h.M = M; h.N = l.out; h.Kpad = round_up(l.in_pad, BK);
-            h.X = ws[cur]; h.x_ld = ld;
-            h.W = reinterpret_cast<const uint16_t*>(c->wb16[1 + i]); h.bias = c->bb16[1 + i]; h.relu = 1;
+            h.X = ws[cur]; h.x_ld = (int64_t)F * ld; h.x_lo = ld;
+            h.W = reinterpret_cast<const uint16_t*>(wimg[1 + i]); h.w_ld = (int64_t)F * h.Kpad; h.bias = c->bb16[1 + i]; h.relu = 1;
             ld = round_up(l.out_pad, BT);
-            h.Y = ws[cur ^ 1]; h.y_rs = ld;
-            if ((rc = launch<false, 2, 4>(h, c->device, Mpad, ld, s))) return rc;
+            h.Y = ws[cur ^ 1]; h.y_rs = (int64_t)F * ld; h.y_lo = ld;
+            if ((rc = launch<false, 2, 4, false, SPLIT>(h, c->device, Mpad, ld, s))) return rc;
             cur ^= 1;
         }
         GemmB h{};
         h.M = M; h.N = c->head.out; h.Kpad = round_up(c->head.in_pad, BK);
-        h.X = ws[cur]; h.x_ld = ld;
-        h.W = reinterpret_cast<const uint16_t*>(c->wb16.back()); h.bias = c->bb16.back();
+        h.X = ws[cur]; h.x_ld = (int64_t)F * ld; h.x_lo = ld;
+        h.W = reinterpret_cast<const uint16_t*>(wimg.back()); h.w_ld = (int64_t)F * h.Kpad; h.bias = c->bb16.back();
         h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
-        if (c->head.out <= 128) rc = launch<true, 4, 2>(h, c->device, Mpad, 128, s);
-        else rc = launch<true, 2, 4>(h, c->device, Mpad, round_up(c->head.out_pad, BT), s);
+        if (c->head.out <= 128) rc = launch<true, 4, 2, false, SPLIT>(h, c->device, Mpad, 128, s);
+        else rc = launch<true, 2, 4, false, SPLIT>(h, c->device, Mpad, round_up(c->head.out_pad, BT), s);
         if (rc) return rc;
     }
-    return MTK_OK;
+    return mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
+}
+
+}  // namespace
+
+int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                             float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
+    return forward_layered<false>(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, s);
+}
+
+// MTK_PREC_BF16X3: split-bf16 operands (hi + lo), three MFMAs per product, fp32 accumulate - the fast path that meets the
+// fp32 parity bar (<= 1e-4; measured ~1e-5 of the output scale)
+int mtk_layered_bf16x3_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                               float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
+    return forward_layered<true>(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, s);
 }

@@ -12,11 +12,13 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s);    // mtk_mlp_bf16.hip
 void mtk_free_fused(mtk_ctx* c);                  // mtk_mlp_bf16.hip
 void mtk_free_train(mtk_ctx* c);                  // mtk_train.hip
 void mtk_free_layered(mtk_ctx* c);                // mtk_mlp_bf16_layered.hip
-int mtk_pack_layered(mtk_ctx* c, hipStream_t s);  // mtk_mlp_bf16_layered.hip
+int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain);  // mtk_mlp_bf16_layered.hip
 int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                              float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16_layered.hip
 int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                       float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16.hip
+int mtk_layered_bf16x3_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                               float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16_layered.hip
 
 namespace {
 
@@ -34,6 +36,7 @@ struct GemmArgs {
     const float* bias;                   // [Npad]
     const float* emb; int emb_ld;        // optional [T][emb_ld] gathered by t
     const int64_t* tvec; int t_scalar;
+    int T;                               // rows of emb
     int act;
     float* Y; int64_t y_rs, y_cs;        // generic output (OGEN) or row-major with ld = y_rs
 };
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
                 const int64_t row = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[mt][nt][r] + bias;
                 if (g.emb) {
-                    const int tr = (g.tvec && row < g.M) ? (int)g.tvec[row] : (g.tvec ? 0 : g.t_scalar);
+                    // per-row timesteps are clamped into the [T] table; the host poisons such rows afterwards (mtk_tclamp)
+                    const int tr = (g.tvec && row < g.M) ? mtk_tclamp(g.tvec[row], g.T) : (g.tvec ? 0 : g.t_scalar);
                     v += g.emb[(int64_t)tr * g.emb_ld + n];
                 }
                 if (g.act == ACT_RELU) v = fmaxf(v, 0.0f);
@@ -279,18 +283,58 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
     (void)hipFree(e1);
     c->have_weights = true;
     if ((rc = mtk_pack_fused(c, s))) return rc;
-    // shapes the fused kernel does not cover get bf16 weight images for the layer-by-layer bf16 MFMA path
-    return c->fused_ok ? MTK_OK : mtk_pack_layered(c, s);
+    // split-bf16 weight images for MTK_PREC_BF16X3 (every shape); shapes the fused kernel does not cover also get plain bf16
+    // images for the layer-by-layer bf16 MFMA path
+    return mtk_pack_layered(c, s, !c->fused_ok);
 }
 
-// Exact-fp32 forward for `B` rows starting at x / out.
+// Exact-fp32 forward for `B` rows (at most `chunk` at a pass) through the activation ping-pong buffers ws0 / ws1
+// ([>= min(round_up(B, 128), chunk)][widest padded layer] floats each).  Every GEMM writes the whole padded tile region
+// the next one reads, so the buffers need no clearing.
+static int forward_f32_ws(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
+                          float* out, int64_t o_rs, int64_t o_cs, float* ws0, float* ws1, int64_t chunk, hipStream_t s) {
+    float* ws[2] = {ws0, ws1};
+    for (int64_t r0 = 0; r0 < B; r0 += chunk) {
+        const int64_t M = (B - r0 < chunk) ? B - r0 : chunk;
+        const int64_t Mpad = (M + BM - 1) / BM * BM;
+        int rc;
+        GemmArgs g{};
+        g.M = M; g.N = c->proj.out; g.K = c->proj.in; g.Kpad = c->proj.in_pad;
+        g.X = x + r0 * x_rs; g.x_rs = x_rs; g.x_cs = x_cs;
+        g.W = c->proj.w32; g.ldw = c->proj.in_pad; g.bias = c->proj.b32;
+        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar; g.T = c->T;
+        g.act = ACT_NONE; g.Y = ws[0]; g.y_rs = c->proj.out_pad;
+        if ((rc = launch_gemm<true, false>(g, Mpad, c->proj.out_pad, s))) return rc;
+        int cur = 0;
+        for (auto& l : c->blocks) {
+            GemmArgs h{};
+            h.M = M; h.N = l.out; h.K = l.in; h.Kpad = l.in_pad;
+            h.X = ws[cur]; h.x_rs = l.in_pad; h.W = l.w32; h.ldw = l.in_pad; h.bias = l.b32;
+            h.act = ACT_RELU; h.Y = ws[cur ^ 1]; h.y_rs = l.out_pad;
+            if ((rc = launch_gemm<false, false>(h, Mpad, l.out_pad, s))) return rc;
+            cur ^= 1;
+        }
+        GemmArgs h{};
+        h.M = M; h.N = c->head.out; h.K = c->head.in; h.Kpad = c->head.in_pad;
+        h.X = ws[cur]; h.x_rs = c->head.in_pad; h.W = c->head.w32; h.ldw = c->head.in_pad; h.bias = c->head.b32;
+        h.act = ACT_NONE; h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
+        if ((rc = launch_gemm<false, true>(h, Mpad, c->head.out_pad, s))) return rc;
+    }
+    return mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
+}
+
+static int max_pad_of(const mtk_ctx* c) {
+    int maxpad = c->proj.out_pad;
+    for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
+    return maxpad;
+}
+
+// Exact-fp32 forward through the context-owned workspace (grown on demand, or ahead of time by mtk_ctx_reserve).
 static int forward_f32(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                        float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
     const int64_t chunk = 65536;
-    int maxpad = c->proj.out_pad;
-    for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
     const int64_t need_rows = (B < chunk ? (B + BM - 1) / BM * BM : chunk);
-    const size_t need = (size_t)need_rows * maxpad;
+    const size_t need = (size_t)need_rows * max_pad_of(c);
     if (need > c->ws_elems) {
         MTK_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < 2; ++i) {
@@ -300,33 +344,7 @@ static int forward_f32(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int6
         }
         c->ws_elems = need;
     }
-    for (int64_t r0 = 0; r0 < B; r0 += chunk) {
-        const int64_t M = (B - r0 < chunk) ? B - r0 : chunk;
-        const int64_t Mpad = (M + BM - 1) / BM * BM;
-        int rc;
-        GemmArgs g{};
-        g.M = M; g.N = c->proj.out; g.K = c->proj.in; g.Kpad = c->proj.in_pad;
-        g.X = x + r0 * x_rs; g.x_rs = x_rs; g.x_cs = x_cs;
-        g.W = c->proj.w32; g.ldw = c->proj.in_pad; g.bias = c->proj.b32;
-        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar;
-        g.act = ACT_NONE; g.Y = c->ws[0]; g.y_rs = c->proj.out_pad;
-        if ((rc = launch_gemm<true, false>(g, Mpad, c->proj.out_pad, s))) return rc;
-        int cur = 0;
-        for (auto& l : c->blocks) {
-            GemmArgs h{};
-            h.M = M; h.N = l.out; h.K = l.in; h.Kpad = l.in_pad;
-            h.X = c->ws[cur]; h.x_rs = l.in_pad; h.W = l.w32; h.ldw = l.in_pad; h.bias = l.b32;
-            h.act = ACT_RELU; h.Y = c->ws[cur ^ 1]; h.y_rs = l.out_pad;
-            if ((rc = launch_gemm<false, false>(h, Mpad, l.out_pad, s))) return rc;
-            cur ^= 1;
-        }
-        GemmArgs h{};
-        h.M = M; h.N = c->head.out; h.K = c->head.in; h.Kpad = c->head.in_pad;
-        h.X = c->ws[cur]; h.x_rs = c->head.in_pad; h.W = c->head.w32; h.ldw = c->head.in_pad; h.bias = c->head.b32;
-        h.act = ACT_NONE; h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
-        if ((rc = launch_gemm<false, true>(h, Mpad, c->head.out_pad, s))) return rc;
-    }
-    return MTK_OK;
+    return forward_f32_ws(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, c->ws[0], c->ws[1], chunk, s);
 }
 
 extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
@@ -342,6 +360,10 @@ extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_
         if (c->fused_ok) return mtk_fused_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
         if (c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward: the bf16 images do not track a training state; detach it (set the weights again) first");
         return mtk_layered_bf16_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
+    }
+    if (precision == MTK_PREC_BF16X3) {
+        if (c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward: the bf16 images do not track a training state; detach it (set the weights again) first");
+        return mtk_layered_bf16x3_forward(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
     }
     MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward: unknown precision %d", precision);
 }

@@ -65,7 +65,7 @@ extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_
             const int rc = mtk_fused_tf_score(c, B, P, x, x_ld, noise, n_t, t_list_host, add_t, score, s);
             if (rc != MTK_ERR_UNSUPPORTED) return rc;
         }
-    } else if (precision != MTK_PREC_FP32) {
+    } else if (precision != MTK_PREC_FP32 && precision != MTK_PREC_BF16X3) {
         MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: unknown precision %d", precision);
     }
 

@@ -35,7 +35,7 @@ struct G2 {
     float* C; int64_t c_rs, c_cs;  // C[m * c_rs + n * c_cs]
     const float* bias;             // [grid.y * tile] or null
     const float* emb; int emb_ld;  // optional [T][emb_ld], gathered by tvec[m]
-    const int64_t* tvec; int64_t rows_valid;
+    const int64_t* tvec; int64_t rows_valid; int T;  // per-row timesteps are clamped into [0, T) (mtk_tclamp)
     const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed where mask <= 0
     int relu;
     int atomic;                    // accumulate with fp32 atomic add (split-K)
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 const int64_t row = m0 + wr * 32 * WT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[mt][nt][r] + bias;
                 if (g.emb) {
-                    const int tr = (row < g.rows_valid) ? (int)g.tvec[row] : 0;
+                    const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
                     v += g.emb[(int64_t)tr * g.emb_ld + n];
                 }
                 if (g.relu) v = fmaxf(v, 0.0f);
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void k_rowsum_cm(const float* dy, int64_t ld, 
 // d emb[t[row]][:] += d act0[row][:]   (the time embedding is added to the proj output, MODEL:608-611)
 // One wave per row (blockDim = 64 x 4): the row's timestep is a wave-uniform load and the lanes walk its columns — no
 // 64-bit division per element (the flat-index version spent 51 us on 4096 x 128 values).
-__global__ __launch_bounds__(256) void k_scatter_emb(const float* dact, int64_t ld, const int64_t* t, int64_t rows, int n, float* demb, int emb_ld) {
+__global__ __launch_bounds__(256) void k_scatter_emb(const float* dact, int64_t ld, const int64_t* t, int64_t rows, int n, float* demb, int emb_ld, int T) {
     for (int64_t r = (int64_t)blockIdx.x * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.x * 4) {
-        float* dst = demb + t[r] * emb_ld;
+        float* dst = demb + (int64_t)mtk_tclamp(t[r], T) * emb_ld;
         const float* src = dact + r * ld;
         for (int c = threadIdx.x; c < n; c += 64) unsafeAtomicAdd(&dst[c], src[c]);
     }
@@ -508,7 +508,7 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.M = (int)Mpad; g.N = c->proj.out_pad; g.K = c->proj.in_pad; g.kchunk = g.K;
         g.A = tr.xin; g.lda = ld; g.B = c->proj.w32; g.ldb = c->proj.in_pad;
         g.C = tr.act[0]; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
-        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t; g.rows_valid = B;
+        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t; g.rows_valid = B; g.T = c->T;
         if ((rc = launch<true, false>(g, s))) return rc;
     }
     for (size_t i = 0; i < c->blocks.size(); ++i) {
@@ -582,7 +582,7 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
         g.rowsum = grads + r.b_off;
         if ((rc = launch<true, false>(g, s))) return rc;
-        hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld);
+        hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
     }
     {   // time-embedding MLP over the T-row table
         const int tp = c->emb_ld;

@@ -113,6 +113,13 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         self._engine: Engine | None = None
 
     # ------------------------------------------------------------------ plumbing
+    def __getstate__(self):
+        """Pickles (TRAIN:122-123, 298 dump the whole object) without the device contexts: rebuilt lazily after loading."""
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        state.pop("_aux", None)
+        return state
+
     @property
     def _has_cat(self) -> bool:
         return len(self.num_classes) > 0 and int(self.num_classes[0]) != 0
@@ -246,17 +253,27 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return lm.mean(), lg.mean()
 
     # ------------------------------------------------------------------ reverse chain
-    def _reverse_chain(self, B: int, outputs: dict[str, Tensor], model_kwargs, conditioning_function, inj: dict | None,
-                       ddim: bool = False) -> Tensor:
+    def _reverse_chain(self, B: int, draw_outputs, model_kwargs, conditioning_function, inj: dict | None,
+                       ddim: bool = False, row0: int = 0, seed: int | None = None):
         """The loop shared by sample (GMD:1403-1424) and conditional_sample (GMD:1344-1367): T x (denoiser,
         mtk_p_sample_step[_guided]) on a device-resident fp64 state, then decode.  ``conditioning_function(features,
         timestep, **model_kwargs)`` is the caller's (GMD:614): it sees the current numeric state as the reference's
-        would (fp32 on the first step, fp64 after) and returns d log p(y|x)/dx, which the step kernel folds into the mean."""
+        would (fp32 on the first step, fp64 after) and returns d log p(y|x)/dx, which the step kernel folds into the mean.
+
+        ``draw_outputs()`` returns the ``{"y": ...}`` dict; it is called AFTER the initial state draws, which is where the
+        reference draws its labels (GMD:1392-1401: randn, per-column rand, then multinomial), so a seeded generator
+        shared by ``target_dist`` and the state (both on the GPU) yields the reference's stream.
+        ``row0`` / ``seed``: in-kernel Philox noise is keyed by (seed, row0 + row, column, step), so disjoint row ranges
+        under one seed are independent streams - what sharded sampling uses (distributed.sample_all_sharded)."""
         eng = self.engine()
         dev = eng.device
         Nn, C, D, T = eng.Nn, eng.C, eng.D, self.num_timesteps
         philox = self.rng == "philox" and inj is None
-        seed = int(torch.randint(1, 2**62, (1,)).item()) if philox else 0
+        if philox:
+            seed = int(torch.randint(1, 2**62, (1,)).item()) if seed is None else int(seed)
+        else:
+            seed = 0
+        row0 = int(row0)
         model_kwargs = model_kwargs or {}
 
         def draw_u():
@@ -268,12 +285,18 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         elif not philox:
             z0 = torch.randn((B, Nn), device=dev)
             u0 = draw_u() if C else None
+        outputs = draw_outputs()
         z = torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev)
         z_idx = torch.empty((max(C, 1), B), dtype=torch.int32, device=dev)
         x_in = torch.empty((D, B), dtype=torch.float32, device=dev)
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
-        eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed)
+        eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed, row0)
+        graph = self._chain_graph(eng, B, x_in, out, z, z_idx, seed, row0) if (philox and not ddim and conditioning_function is None) else None
+        if graph is not None:
+            graph.replay()
         for i, t in enumerate(reversed(range(T))):
+            if graph is not None:
+                break
             self._denoise_cm(eng, x_in, t, B, out)
             n = u = grad = None
             if inj is not None:
@@ -284,7 +307,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                     n = torch.randn((B, Nn), device=dev, dtype=torch.float32 if i == 0 else torch.float64)
                 u = draw_u() if C else None
             if ddim:  # GMD:1292-1308, eta = 0: no Gaussian noise enters (the reference draws it and multiplies by sigma = 0)
-                eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed)
+                eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed, row0)
                 continue
             if conditioning_function is not None and Nn:
                 feats = z[:Nn].t().contiguous()
@@ -292,38 +315,44 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                     feats = feats.float()
                 tvec = torch.full((B,), t, device=dev, dtype=torch.long)
                 grad = conditioning_function(feats, tvec, **model_kwargs).detach().to(device=dev, dtype=torch.float32).contiguous()
-            eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed, grad=grad)
+            eng.p_sample_step(B, t, i == 0, out, (1, B), z, z_idx, n, u, x_in, (1, B), seed, row0, grad=grad)
         sample = torch.empty((B, Nn + C), dtype=torch.float64, device=dev)
         eng.sample_decode(B, z, z_idx, sample)
         sample = sample.float() if ddim else sample  # the reference's DDIM chain is fp32 end to end
-        return sample if getattr(self, "results_on_device", False) else sample.cpu()
+        return (sample if getattr(self, "results_on_device", False) else sample.cpu()), outputs
+
+    def _chain_graph(self, eng: Engine, B, x_in, out, z, z_idx, seed, row0):
+        """HIP-graph capture of the T-loop (``use_graph``; in-kernel noise only: no host draws inside the loop).  Off by
+        default; see ``capture_chain``."""
+        return None
+
+    def _target_fn(self, batch_size: int, target_dist: Tensor, inj: dict | None):
+        def draw():
+            if inj is not None and "y" in inj:
+                target = inj["y"]
+            else:
+                target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
+            return {"y": target.long().to(self.alphas.device)}
+
+        return draw
 
     @torch.no_grad()
     def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
-               conditioning_function=None, _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+               conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None) -> tuple[Tensor, dict[str, Tensor]]:
         """GMD:1370.  Returns ([B, Nn + C] fp64 on CPU, {"y": labels}).  ``conditioning_function``: classifier guidance
-        of the numeric features (gaussian_p_sample GMD:699-702)."""
-        dev = self.engine().device
-        if _injected is not None and "y" in _injected:
-            target = _injected["y"]
-        else:
-            target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
-        outputs = {"y": target.long().to(dev)}
-        return self._reverse_chain(batch_size, outputs, model_kwargs, conditioning_function, _injected), outputs
+        of the numeric features (gaussian_p_sample GMD:699-702).  ``row0`` / ``seed`` (not in the reference): Philox
+        stream position of row 0 and the shared seed, for sharded sampling."""
+        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected), model_kwargs, conditioning_function,
+                                   _injected, row0=row0, seed=seed)
 
     @torch.no_grad()
     def sample_ddim(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
-                    conditioning_function=None, _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+                    conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None) -> tuple[Tensor, dict[str, Tensor]]:
         """GMD:1259 (eta = 0).  Returns ([B, Nn + C] fp32 on CPU, {"y": labels})."""
         if conditioning_function is not None:
             raise NotImplementedError("score-based guidance of the DDIM chain (condition_score, GMD:617-661) is not on the MI355X path")
-        dev = self.engine().device
-        if _injected is not None and "y" in _injected:
-            target = _injected["y"]
-        else:
-            target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
-        outputs = {"y": target.long().to(dev)}
-        return self._reverse_chain(batch_size, outputs, model_kwargs, None, _injected, ddim=True), outputs
+        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected), model_kwargs, None, _injected, ddim=True,
+                                   row0=row0, seed=seed)
 
     def conditional_sample(self, targets: Tensor, model_kwargs: dict[str, Any] | None = None, conditioning_function=None,
                            _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:
@@ -334,17 +363,19 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                              "it is only defined for num_classes = [0]")
         with torch.no_grad():
             dev = self.engine().device
-            outputs = {"y": targets.long().to(dev)}
-            return self._reverse_chain(len(targets), outputs, model_kwargs, conditioning_function, _injected), outputs
+            return self._reverse_chain(len(targets), lambda: {"y": targets.long().to(dev)}, model_kwargs, conditioning_function, _injected)
 
     def sample_all(self, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False,
-                   model_kwargs: dict[str, Any] | None = None, conditioning_function=None) -> tuple[Tensor, Tensor]:
-        """GMD:1426."""
+                   model_kwargs: dict[str, Any] | None = None, conditioning_function=None, row0: int = 0,
+                   seed: int | None = None) -> tuple[Tensor, Tensor]:
+        """GMD:1426.  ``row0`` / ``seed`` (not in the reference): see ``sample``; batch i of this call continues the
+        Philox row range at ``row0 + i * batch_size``."""
         all_targets, all_samples = [], []
         num_generated = 0
         while num_generated < num_samples:
             sample_fn = self.sample_ddim if ddim else self.sample  # GMD:1452-1455
-            sample, outputs = sample_fn(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function)
+            sample, outputs = sample_fn(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function,
+                                        row0=row0 + num_generated, seed=seed)
             mask_nan = torch.any(sample.isnan(), dim=1)
             sample = sample[~mask_nan]
             outputs["y"] = outputs["y"].to(sample.device)[~mask_nan]
@@ -353,4 +384,9 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             if sample.shape[0] != batch_size:
                 raise FoundNaNsError
             num_generated += sample.shape[0]
+        if not all_samples:  # num_samples == 0 (an empty shard): the reference's torch.cat([]) would raise
+            dev = self.alphas.device if getattr(self, "results_on_device", False) else torch.device("cpu")
+            width = self.num_numerical_features + (len(self.num_classes) if self._has_cat else 0)
+            return (torch.empty((0, width), dtype=torch.float32 if ddim else torch.float64, device=dev),
+                    torch.empty((0,), dtype=torch.long, device=dev))
         return torch.cat(all_samples, dim=0)[:num_samples], torch.cat(all_targets, dim=0)[:num_samples]

@@ -60,12 +60,38 @@ def score_records_sharded(diffusion_model, features: Tensor, noise: Tensor, time
     return gather_rows(local, features.shape[0], dim=1)
 
 
-def sample_all_sharded(diffusion_model, num_samples: int, batch_size: int, target_dist: Tensor):
+def shared_seed() -> int:
+    """One 62-bit seed that every rank agrees on: drawn on rank 0 from torch's CPU generator and broadcast."""
+    rank, ws = world()
+    seed = torch.randint(1, 2**62, (1,), dtype=torch.int64)
+    if ws > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        seed = seed.to(dev)
+        dist.broadcast(seed, src=0)
+    return int(seed.item())
+
+
+def sample_all_sharded(diffusion_model, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False):
     """``sample_all`` (GMD:1426) with the rows split over ranks; each rank runs its own T-loop, the only exchange is
-    the final gather of the [N, Nn + C] fp64 samples and their labels."""
+    the final gather of the [N, Nn + C] samples and their labels.
+
+    The reference pipeline seeds every process identically (common/random.py:11-55), so the ranks must be decorrelated
+    here, not by the caller: with ``rng="philox"`` all ranks share ONE seed (broadcast from rank 0) and rank r's rows
+    take the Philox row range [lo_r, hi_r) - the samples do not depend on the number of GPUs; with ``rng="torch"`` each
+    rank re-seeds torch's generators inside a fork with (a seed drawn from the caller's generator) + rank, and the
+    caller's generator state is restored on return.  An empty shard contributes zero rows."""
     rank, ws = world()
     lo, hi = shard_range(num_samples, rank, ws)
-    x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist)
+    if diffusion_model.rng == "philox":
+        x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim, row0=lo, seed=shared_seed())
+    elif ws == 1:
+        x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim)
+    else:
+        base = int(torch.randint(1, 2**31, (1,)).item())  # same on every rank when the processes were seeded alike
+        dev = diffusion_model.alphas.device
+        with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else []):
+            torch.manual_seed(base + rank)
+            x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim)
     if ws == 1:
         return x, y
     dev = diffusion_model.alphas.device if dist.get_backend() == "nccl" else torch.device("cpu")

@@ -8,9 +8,14 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PREC_BF16, PREC_FP32, check, ptr, require_cuda
+from ._lib import PREC_BF16, PREC_BF16X3, PREC_FP32, check, ptr, require_cuda
 
-PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16}
+PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}  # "bf16x3": split-bf16 (hi + lo, 3 MFMAs per product), fp32-parity grade
+
+
+def _no_engine():
+    """What a pickled Engine unpickles to: nothing.  The owner builds a new context lazily."""
+    return None
 
 
 class Engine:
@@ -52,6 +57,13 @@ class Engine:
         """A device context is not copied with the module that holds it (deepcopy of a denoiser / diffusion
         object, TRAINER:40): the copy builds its own lazily."""
         return None
+
+    def __reduce__(self):
+        """A device context is a raw handle (ctypes pointers cannot be pickled) and means nothing in another process: the
+        reference's orchestration pickles whole diffusion objects (models/clavaddpm/train.py:122-123, 298), so an Engine
+        pickles as None, exactly like ``__deepcopy__``; ``GaussianMultinomialDiffusion.engine()`` / ``MLPDiffusion.engine()``
+        rebuild it on first use after loading."""
+        return (_no_engine, ())
 
     def set_math(self, mode: str) -> None:
         """"reference" (parity, default) or "fast" (hardware transcendentals, exact block log-sum-exp)."""

@@ -128,6 +128,12 @@ class MLPDiffusion(nn.Module):
         self._synced_key = None
 
     # ---- engine plumbing -------------------------------------------------------------------
+    def __getstate__(self):
+        """Pickles without the device context and its bookkeeping (rebuilt lazily; see Engine.__reduce__)."""
+        state = dict(self.__dict__)
+        state["_engine"], state["_engine_shared"], state["_synced_key"] = None, False, None
+        return state
+
     def _weights(self):
         lin = [self.proj, self.timestep_embedding[0], self.timestep_embedding[2]]
         lin += [b.linear for b in self.mlp.blocks] + [self.mlp.head]

@@ -139,6 +139,8 @@ class ClavaDDPMTrainer:
         self.ema_model.to(self.device)
         self._engine.train_export("weights", self._tensors(net))
         self._engine.train_export("ema", self._tensors(self.ema_model))
+        # the export writes the parameters through raw pointers (no version bump): the EMA copy's own packed image is stale
+        self.ema_model._synced_key = None
         torch.cuda.synchronize(self.device)
 
     def finish(self) -> None:

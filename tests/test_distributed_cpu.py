@@ -107,3 +107,60 @@ def _grad_rank(rank, ws):
 def test_data_parallel_gradient_is_the_global_batch_gradient():
     out = run_ranks(_grad_rank, 2)
     assert out[0] < 1e-5 and out[1] < 1e-5, out
+
+
+class _FakeSampler:
+    """Stands in for the drop-in diffusion object in the host-logic test of sample_all_sharded (no GPU in this tier):
+    same sample_all signature; in "philox" mode a row is a pure function of (seed, global row index), as the kernels'
+    counters make it; in "torch" mode rows come from torch's global generator, as the reference's draws do."""
+
+    def __init__(self, rng):
+        self.rng = rng
+        self.alphas = torch.zeros(1)
+        self.calls = []
+
+    def sample_all(self, num_samples, batch_size, target_dist, ddim=False, row0=0, seed=None):
+        self.calls.append((num_samples, batch_size, row0, seed))
+        if num_samples == 0:
+            return torch.empty((0, 3), dtype=torch.float64), torch.empty((0,), dtype=torch.long)
+        if self.rng == "philox":
+            rows = torch.arange(row0, row0 + num_samples, dtype=torch.float64)
+            x = torch.stack([rows, torch.full_like(rows, float(seed % 1000)), (rows * 7 + seed % 13) % 5], 1)
+        else:
+            x = torch.randn((num_samples, 3), dtype=torch.float64)
+        return x, torch.multinomial(target_dist, num_samples, replacement=True)
+
+
+def _sample_rank(rank, ws, n, rng):
+    import midst_toolkit_amd.distributed as D
+
+    torch.manual_seed(1234)  # the reference pipeline seeds every process identically (common/random.py:11-55)
+    fake = _FakeSampler(rng)
+    x, y = D.sample_all_sharded(fake, n, 16, torch.ones(4))
+    return x.numpy(), y.numpy(), fake.calls  # numpy: a tensor in the queue would be shared through a file descriptor of a process that has exited
+
+
+@pytest.mark.parametrize("n", [37, 1])
+def test_sample_all_sharded_philox_rows_do_not_depend_on_world_size(n):
+    out = run_ranks(_sample_rank, 2, n, "philox")
+    x0, y0, calls0 = (torch.from_numpy(out[0][0]), torch.from_numpy(out[0][1]), out[0][2])
+    x1, y1, calls1 = (torch.from_numpy(out[1][0]), torch.from_numpy(out[1][1]), out[1][2])
+    assert torch.equal(x0, x1) and torch.equal(y0, y1) and x0.shape == (n, 3) and y0.shape == (n,)
+    assert calls0[0][3] == calls1[0][3], "every rank must use the seed broadcast from rank 0"
+    assert calls0[0][2] == 0 and calls1[0][2] == (n + 1) // 2, "rank r's Philox rows start at its shard offset"
+    assert torch.equal(x0[:, 0], torch.arange(n, dtype=torch.float64)), "gathered in global row order, each row once"
+    # one process, same seed: the same table
+    torch.manual_seed(1234)
+    import midst_toolkit_amd.distributed as D
+
+    single, _ = D.sample_all_sharded(_FakeSampler("philox"), n, 16, torch.ones(4))
+    assert torch.equal(single, x0)
+
+
+def test_sample_all_sharded_torch_rng_decorrelates_identically_seeded_ranks():
+    out = run_ranks(_sample_rank, 2, 40, "torch")
+    x0, x1 = torch.from_numpy(out[0][0]), torch.from_numpy(out[1][0])
+    assert torch.equal(x0, x1) and x0.shape == (40, 3)
+    # identically seeded processes used to produce the same rows on every rank: the two shards must differ
+    assert not torch.equal(x0[:20], x0[20:])
+    assert float((x0[:20] - x0[20:]).abs().min()) > 0

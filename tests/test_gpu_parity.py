@@ -48,11 +48,15 @@ def close(got, want, rtol=RTOL, atol=1e-6):
     assert bool(ok.all()), f"max abs err {float(err.max()):.3e}, max rel {float((err / want.abs().clamp_min(1e-9)).max()):.3e}"
 
 
-def check_categorical(got_idx, want_idx, logits, u, K):
-    """Equal, or a Gumbel near-tie in the reference's own arithmetic."""
+def check_categorical(got_idx, want_idx, logits, u, K, exact=False):
+    """``exact`` (the reference fixtures, reference math): every draw equals the reference's.  Otherwise (fast math, big
+    random batches): equal, or a Gumbel near-tie in the reference's own arithmetic, rarer than 1e-3 of the decisions."""
     got_idx, want_idx = got_idx.cpu().long(), want_idx.cpu().long()
     diff = got_idx != want_idx
     n_bad = int(diff.sum())
+    if exact:
+        assert n_bad == 0, f"{n_bad} of {diff.numel()} categorical draws differ from the reference's (bit-exact bar)"
+        return
     assert n_bad <= max(1, int(1e-3 * diff.numel())), f"{n_bad} of {diff.numel()} categorical draws differ"
     if n_bad:
         off = orc.offsets_of(K)
@@ -63,14 +67,62 @@ def check_categorical(got_idx, want_idx, logits, u, K):
             assert float(top2[0] - top2[1]) < TIE_MARGIN, f"row {r} block {k}: differs without a near-tie ({blk.tolist()})"
 
 
+def ranking_report(got, want):
+    """How the ordering of the records by ``got`` differs from their ordering by ``want`` ([B, P], one ranking per noise
+    draw): positions that differ, the largest relative gap between two reference scores that come out swapped, Spearman
+    rho, Kendall tau (by sampling pairs on big batches) and the overlap of the top 10 % sets."""
+    got, want = got.double().cpu(), want.double().cpu()
+    B, P = got.shape
+    order_g = torch.argsort(got, dim=0, stable=True)
+    order_w = torch.argsort(want, dim=0, stable=True)
+    moved = int((order_g != order_w).sum())
+    ref_sorted = torch.gather(want, 0, order_g)
+    drop = (ref_sorted[:-1] - ref_sorted[1:]) / ref_sorted[:-1].abs().clamp_min(1e-30)
+    worst_swap = float(drop.clamp_min(0).max()) if B > 1 else 0.0
+    rank_g = torch.argsort(order_g, dim=0).double()
+    rank_w = torch.argsort(order_w, dim=0).double()
+    rg, rw = rank_g - rank_g.mean(0), rank_w - rank_w.mean(0)
+    spearman = float(((rg * rw).sum(0) / (rg.norm(dim=0) * rw.norm(dim=0)).clamp_min(1e-30)).min()) if B > 1 else 1.0
+    gen = torch.Generator().manual_seed(0)
+    n_pairs = min(200_000, B * (B - 1) // 2) if B > 1 else 0
+    if n_pairs and B * (B - 1) // 2 <= 200_000:
+        i, j = torch.triu_indices(B, B, 1)
+    elif n_pairs:
+        i = torch.randint(0, B, (n_pairs,), generator=gen)
+        j = torch.randint(0, B, (n_pairs,), generator=gen)
+    if n_pairs:
+        sg = torch.sign(got[i] - got[j])
+        sw = torch.sign(want[i] - want[j])
+        valid = (sw != 0)
+        kendall = float(((sg * sw)[valid]).mean())
+        discordant = float(((sg * sw)[valid] < 0).double().mean())
+    else:
+        kendall, discordant = 1.0, 0.0
+    k = max(1, B // 10)
+    top = min(len(set(order_g[-k:, p].tolist()) & set(order_w[-k:, p].tolist())) / k for p in range(P))
+    return {"positions_moved": moved, "positions": B * P, "worst_swapped_gap": worst_swap, "spearman": spearman, "kendall": kendall,
+            "discordant_pairs": discordant, "top10_overlap": top}
+
+
 def check_ranking(got, want, tie=4e-6):
-    """Ordering the records by the GPU score orders the reference scores too, except where two
-    reference scores are closer than `tie` relative (fp32 summation-order noise)."""
+    """Membership-score ranking (north_star: bit-exact given the same injected noise): ordering the records by the GPU
+    score must be the reference's ordering, except between records whose REFERENCE scores are closer than `tie` relative
+    - the documented ties: fp32 summation-order noise of the denoiser GEMMs, ~1e-6, decides those in the reference too.
+    Every position that differs must belong to such a tie group."""
+    got, want = got.cpu(), want.cpu()
     order = torch.argsort(got, dim=0, stable=True)
     ref_sorted = torch.gather(want, 0, order)
     drop = ref_sorted[:-1] - ref_sorted[1:]
     assert bool((drop <= tie * ref_sorted[:-1].abs()).all()), float((drop / ref_sorted[:-1].abs()).max())
-    assert float((order == torch.argsort(want, dim=0, stable=True)).float().mean()) > 0.9
+    want_order = torch.argsort(want, dim=0, stable=True)
+    moved = order != want_order
+    if bool(moved.any()):  # a moved position holds a record whose reference score ties (within `tie`) with a neighbour's
+        ws = torch.gather(want, 0, want_order)
+        gap_lo = torch.cat([torch.full_like(ws[:1], float("inf")), (ws[1:] - ws[:-1]) / ws[1:].abs()], 0)
+        gap_hi = torch.cat([(ws[1:] - ws[:-1]) / ws[:-1].abs(), torch.full_like(ws[:1], float("inf"))], 0)
+        in_tie = (gap_lo <= tie) | (gap_hi <= tie)
+        assert bool(in_tie[moved].all()), f"{int((moved & ~in_tie).sum())} ranking positions differ outside documented ties"
+    return int(moved.sum())
 
 
 def colmajor(x):
@@ -96,7 +148,7 @@ def test_q_sample(tag):
         if C:
             s = orc.make_schedule(c["T"], c["sched"])
             logits = orc.q_pred(s, orc.log_onehot(tt(c["x0"])[:, c["Nn"]:].long(), c["K"]), tt(c["ml_t"]), orc.log_k_expanded(c["K"]))
-            check_categorical(idx[:C].t(), tt(c["ml_xt_idx"]), logits, tt(c["ml_u"]), c["K"])
+            check_categorical(idx[:C].t(), tt(c["ml_xt_idx"]), logits, tt(c["ml_u"]), c["K"], exact=True)
             same = (idx[:C].t().cpu().long() == tt(c["ml_xt_idx"])).all(dim=1)
             assert torch.equal(x_in_rm.cpu()[same][:, c["Nn"]:], tt(c["ml_model_in"])[same][:, c["Nn"]:])
 
@@ -216,7 +268,7 @@ def test_reverse_steps(tag):
             close(z.t(), tt(c[f"rs{k}_z_new"]), rtol=1e-12 if k else 1e-6, atol=1e-12 if k else 1e-7)
             assert torch.equal(x_next[:Nn].t().cpu(), z.t().float().cpu())
         if C:
-            check_categorical(z_idx.t(), tt(c[f"rs{k}_z_idx_new"]), tt(c[f"rs{k}_logp"]), tt(c[f"rs{k}_u"]), c["K"])
+            check_categorical(z_idx.t(), tt(c[f"rs{k}_z_idx_new"]), tt(c[f"rs{k}_logp"]), tt(c[f"rs{k}_u"]), c["K"], exact=True)
             want_oh = orc.log_onehot(z_idx.t().cpu().long(), c["K"])
             assert torch.equal(x_next[Nn:].t().cpu(), want_oh)
 
@@ -238,8 +290,9 @@ def test_full_chain(tag):
     want = tt(c["ch_sample"])
     assert got.dtype == torch.float64 and got.shape == want.shape and not got.is_cuda
     same = (got[:, Nn:] == want[:, Nn:]).all(dim=1) if C else torch.ones(got.shape[0], dtype=torch.bool)
-    # a flipped Gumbel near-tie changes that row's whole trajectory; the rest must agree
-    assert float(same.float().mean()) >= 0.97, float(same.float().mean())
+    # bit-exact bar on the reference's own chain: every category of every row (a flipped Gumbel near-tie would change
+    # that row's whole trajectory; none flips on these fixtures)
+    assert bool(same.all()), f"{int((~same).sum())} of {same.numel()} rows differ in a category from the reference's chain"
     if Nn:
         # The chain multiplies eps_hat by sqrt_recipm1_alphas_cumprod (up to 2e4) at every step, so the
         # reference's own fp32 denoiser rounding already moves the result: measure that (fp32 vs fp64
@@ -319,7 +372,7 @@ def test_ddim_chain(tag):
     want = tt(c["sample"])
     assert got.dtype == torch.float32 and got.shape == want.shape and not got.is_cuda
     same = (got[:, Nn:] == want[:, Nn:]).all(dim=1) if C else torch.ones(B, dtype=torch.bool)
-    assert float(same.float().mean()) >= 0.97, float(same.float().mean())
+    assert bool(same.all()), f"{int((~same).sum())} of {B} rows differ in a category from the reference's DDIM chain"
     s = orc.make_schedule(T, c["sched"])
     us = [tt(v) for v in c["u"]] if C else [None] * T
     ref64 = orc.sample_chain_ddim(s, c["K"], Nn, case_params(c), tt(c["z0"]), tt(c["u0"]) if C else None, [tt(n) for n in c["noise"]], us,
@@ -381,6 +434,45 @@ def test_bad_arguments_raise():
     with pytest.raises(ValueError):
         d2 = build(load_case("B_ragged"))
         d2.engine().tf_score(torch.zeros((4, 6), device=dev()), torch.zeros((2, 6), device=dev()), [1])
+
+
+def test_out_of_range_timesteps_poison_their_rows():
+    """Per-row timesteps live in device memory the host never reads.  The reference's sinusoid embedding accepts any t;
+    here emb is a [T] table and the schedule rows are [T] too, so a timestep outside [0, T) must be loud and safe: the
+    kernels clamp it for addressing and the row's outputs come back NaN - every other row is untouched."""
+    c = load_case("M_mixed")
+    B, Nn, C, D, T = 300, c["Nn"], c["C"], c["D"], c["T"]
+    x0, t, eps, u = _big_mixed_batch(c, B)
+    bad_rows = [5, 77, 299]
+    t_bad = t.clone()
+    t_bad[5], t_bad[77], t_bad[299] = T, -1, 10**12
+    ok = torch.ones(B, dtype=torch.bool)
+    ok[bad_rows] = False
+    for precision in ("fp32", "bf16"):
+        d = build(c, precision=precision)
+        eng = d.engine()
+        xin = orc.model_input(*orc.q_sample_fused(orc.make_schedule(T, c["sched"]), c["K"], Nn, x0, t, eps, u), c["K"]).to(dev())
+        good = eng.mlp_forward(xin, t.to(dev()), precision=precision)
+        got = eng.mlp_forward(xin, t_bad.to(dev()), precision=precision)
+        assert bool(got[~ok].isnan().all()) and torch.equal(got[ok], good[ok]), precision
+        lm, lg = d.mixed_loss_rows(x0.to(dev()), timestep=t_bad.to(dev()), noise=eps.to(dev()), uniform=u.to(dev()))
+        lm0, lg0 = d.mixed_loss_rows(x0.to(dev()), timestep=t.to(dev()), noise=eps.to(dev()), uniform=u.to(dev()))
+        assert bool(lm[~ok].isnan().all()) and bool(lg[~ok].isnan().all())
+        assert torch.equal(lm[ok], lm0[ok]) and torch.equal(lg[ok], lg0[ok])
+    # layered bf16 path (a shape the fused kernel does not cover)
+    import midst_toolkit_amd as mtk
+
+    net = mtk.MLPDiffusion(24, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([256, 256], 0.0)).to(dev())
+    net.precision = "bf16"
+    xs = torch.randn((B, 24), device=dev())
+    with torch.no_grad():
+        good, got = net(xs, t.to(dev())), net(xs, t_bad.to(dev()))
+    assert bool(got[~ok].isnan().all()) and torch.equal(got[ok], good[ok])
+    # the stand-alone Gaussian helpers: q_sample poisons, the MSE (which does not depend on t) does not
+    xt = d.gaussian_q_sample(x0[:, :Nn].to(dev()), t_bad.to(dev()), eps.to(dev()))
+    assert bool(xt[~ok].isnan().all()) and bool(torch.isfinite(xt[ok]).all())
+    mse = d._gaussian_loss(xt[ok], x0[ok][:, :Nn].to(dev()), xt[ok], t_bad[ok].to(dev()), eps[ok].to(dev()))
+    assert bool(torch.isfinite(mse).all())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -477,6 +569,103 @@ def test_mlp_forward_bf16_layered_many_tiles(shape):
     want = orc.mlp_forward(params, x[pick], t[pick])
     scale = float(want.abs().max())
     assert float((out.cpu()[pick] - want).abs().max()) <= BF16_TOL * scale
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16x3 mode (MTK_PREC_BF16X3): split-bf16 operands (hi + lo), three bf16 MFMAs per product, fp32 accumulate, layer by
+# layer.  This is the fast mode that carries the fp32 bars: denoiser, losses and scores <= 1e-4 relative, score ranking
+# identical to the reference's on the fixtures.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", CASES)
+def test_mlp_forward_bf16x3(tag):
+    c = load_case(tag)
+    d = build(c, precision="bf16x3")
+    x, t = tt(c["ml_model_in"]).to(dev()), tt(c["ml_t"]).to(dev())
+    with torch.no_grad():
+        out = d._denoise_fn(x, t)
+    want = tt(c["ml_model_out"])
+    scale = float(want.abs().max())
+    close(out, want, rtol=RTOL, atol=2e-5 * scale)
+    B, D = x.shape
+    eng = d.engine()
+    o2 = torch.empty((D, B), device=dev())
+    eng.mlp_forward(x.t().contiguous(), t, out=o2, precision="bf16x3", x_strides=(1, B), out_strides=(1, B), B=B)
+    assert torch.equal(o2.t().contiguous(), out)
+    for n in (1, 31, 129):
+        o = eng.mlp_forward(x[:n].contiguous(), t[:n].contiguous(), precision="bf16x3")
+        assert torch.equal(o, out[:n]), n
+
+
+@pytest.mark.parametrize("shape", [(120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512]), (40, [128, 256]), (200, [1536, 768, 2048])])
+def test_mlp_forward_bf16x3_shapes(shape):
+    """The shapes of BASELINE configs 1, 4 and 5 and two odd ones, 70,001 rows (several tiles per workgroup, a second pass
+    through the layer chain): a sample of rows against the oracle at the fp32 bar; windows equal separate small calls."""
+    import midst_toolkit_amd as mtk
+
+    D, layers = shape
+    params = orc.init_mlp_params(D, layers, seed=3)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(layers), 0.0)).to(dev())
+    net.load_state_dict(params, strict=True)
+    net.precision = "bf16x3"
+    g = torch.Generator().manual_seed(2)
+    B = 70_001
+    x = torch.randn((B, D), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    xd, td = x.to(dev()), t.to(dev())
+    with torch.no_grad():
+        out = net(xd, td)
+    pick = torch.randperm(B, generator=g)[:1500]
+    want = orc.mlp_forward(params, x[pick], t[pick])
+    scale = float(want.abs().max())
+    err = float((out.cpu()[pick] - want).abs().max())
+    assert err <= 1e-4 * scale, (err / scale)
+    eng = net.engine(dev())
+    for lo in (0, 256 * 97 + 13, 65_536 - 150, B - 300):
+        o = eng.mlp_forward(xd[lo:lo + 300].contiguous(), td[lo:lo + 300].contiguous(), precision="bf16x3")
+        assert torch.equal(o, out[lo:lo + 300]), lo
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "N_tf"])
+def test_tf_score_bf16x3(tag):
+    from midst_toolkit_amd import scoring
+
+    c = load_case(tag)
+    d = build(c, precision="bf16x3")
+    x0 = tt(c["x0"]).to(dev())
+    noise = tt(c["tf_noise"])
+    P = noise.shape[0]
+    for k in range(4):
+        t, add = (int(v) for v in c[f"tf{k}_t"])
+        got = scoring.mixed_loss(d, x0, {"y": None}, noise.tolist(), P, add, t)
+        want = tt(c[f"tf{k}_score"])
+        close(got, want, rtol=RTOL)
+        if add == 0:  # ranking: the reference's, except inside ties of the reference's own scores (4e-5: ten times the fp32 path's)
+            check_ranking(got.cpu(), want, tie=4e-5)
+
+
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly"])
+def test_mixed_loss_bf16x3(tag):
+    """Whole mixed_loss in the split-bf16 mode against the reference's per-record values: Gaussian rows <= 1e-4; the
+    multinomial rows carry the conditioning floor of tests/test_conditioning.py, per record as in the fp32 test and
+    averaged for the batch mean.  (Why the mean needs it too: on the 96-record B_ragged fixture the REFERENCE's own batch
+    mean moves by up to 4.2e-4 relative when its denoiser output is perturbed by 3e-7 relative - less than fp32 GEMM
+    summation-order noise - because single records move by percents; measured with the oracle, 20 draws.)"""
+    c = load_case(tag)
+    d = build(c, precision="bf16x3")
+    x0 = tt(c["x0"]).to(dev())
+    t = tt(c["ml_t"]).to(dev())
+    eps = tt(c["ml_eps"]).to(dev()) if c["Nn"] else None
+    u = tt(c["ml_u"]).to(dev()) if c["C"] else None
+    lm, lg = d.mixed_loss_rows(x0, timestep=t, noise=eps, uniform=u)
+    if c["Nn"]:
+        close(lg, tt(c["ml_lg_rows"]), rtol=RTOL)
+    if c["C"]:
+        want = tt(c["ml_lm_rows"])
+        s = orc.make_schedule(c["T"], c["sched"])
+        floor = orc.multinomial_loss_floor(s, c["K"], c["Nn"], tt(c["ml_model_out"]), tt(c["x0"]), tt(c["ml_xt_idx"]), tt(c["ml_t"]))
+        err = (lm.cpu().double() - want.double()).abs()
+        assert bool((err <= RTOL * want.abs().double() + 2 * floor).all()), float((err / (RTOL * want.abs().double() + 2 * floor)).max())
+        assert abs(float(lm.mean().cpu()) - float(want.mean())) <= RTOL * abs(float(want.mean())) + 2 * float(floor.mean())
 
 
 def bf16_emulated_forward(params, x, t):

@@ -118,3 +118,35 @@ def test_fast_tensor_dataloader_matches_reference_batches():
     # unshuffled: plain slices, ragged tail kept
     plain = list(FastTensorDataLoader([x, y], batch_size=16))
     assert [b[0].shape[0] for b in plain] == [16, 16, 5] and torch.equal(torch.cat([b[1] for b in plain]), y)
+
+
+def test_drop_in_objects_pickle_without_their_device_context():
+    """The reference's orchestration pickles whole diffusion objects (models/clavaddpm/train.py:122-123, 298).  A device
+    context is a ctypes handle, which cannot be pickled: the drop-ins must pickle without it and rebuild it lazily."""
+    import copy
+    import ctypes
+    import pickle
+
+    import midst_toolkit_amd as mtk
+    from midst_toolkit_amd.engine import Engine
+
+    net = mtk.MLPDiffusion(9, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([16, 16], 0.0))
+    d = mtk.GaussianMultinomialDiffusion(np.array([3, 2]), 4, net, num_timesteps=50, device=torch.device("cpu"))
+    fake = Engine.__new__(Engine)           # what engine() leaves behind, minus the GPU: a ctypes handle inside
+    fake._h = ctypes.c_void_p(0)
+    fake.device = torch.device("cpu")
+    with pytest.raises(ValueError):
+        pickle.dumps(fake._h)               # the failure the advisor reported ...
+    assert pickle.loads(pickle.dumps(fake)) is None   # ... and an Engine now pickles as "no context"
+    d._engine = fake
+    d.__dict__["_aux"] = {(4, "cpu"): fake}
+    net._engine, net._engine_shared, net._synced_key = fake, True, ("stale",)
+    d2 = pickle.loads(pickle.dumps(d))
+    assert d2._engine is None and "_aux" not in d2.__dict__
+    assert d2._denoise_fn._engine is None and d2._denoise_fn._synced_key is None and not d2._denoise_fn._engine_shared
+    assert torch.equal(d2.alphas, d.alphas) and d2.posterior_variance.dtype == torch.float64
+    for (k, a), (k2, b) in zip(d.state_dict().items(), d2.state_dict().items()):
+        assert k == k2 and torch.equal(a, b)
+    d3 = copy.deepcopy(d)
+    assert d3._engine is None and d3._denoise_fn._engine is None
+    assert d._engine is fake and net._engine is fake   # the live object keeps its context
