@@ -115,6 +115,18 @@ int mtk_mlp_set_weights(mtk_ctx* ctx, int n_hidden, const int32_t* dims_host, co
 int mtk_mlp_forward(mtk_ctx* ctx, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
                     int t_scalar, float* out, int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream);
 
+/* No counterpart in the reference: mtk_mlp_forward(MTK_PREC_FP32) for callers that cannot allocate device memory -
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and results as
+ * mtk_mlp_forward with MTK_PREC_FP32, but the activation ping-pong lives in a file-scope device array of the library
+ * (2 x MTK_NOALLOC_MAX_ROWS x MTK_NOALLOC_MAX_WIDTH floats = 32 MiB, held by every GPU the library runs on until the
+ * process ends) instead of the context's hipMalloc'ed workspace; the call allocates, frees and synchronises nothing.
+ * B > MTK_NOALLOC_MAX_ROWS or a hidden layer wider than MTK_NOALLOC_MAX_WIDTH returns MTK_ERR_UNSUPPORTED.  All calls on
+ * one GPU share that GPU's array: calls that overlap on one GPU (two streams, two contexts) race. */
+#define MTK_NOALLOC_MAX_ROWS 4096
+#define MTK_NOALLOC_MAX_WIDTH 1024
+int mtk_mlp_forward_noalloc(mtk_ctx* ctx, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
+                            int t_scalar, float* out, int64_t o_rs, int64_t o_cs, mtk_stream stream);
+
 /* Replaces the noising half of mixed_loss (GMD:1025-1040): gaussian_q_sample (GMD:302),
  * index_to_log_onehot (DU:209), q_pred (GMD:742), log_sample_categorical (GMD:852), q_sample (GMD:873).
  * x0: [B, Nn + C] row-major with leading dimension x0_ld (numeric columns, then category codes as

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("MTK_LIB_PATH") or os.path.join(_HERE, "libmtk_hip.so"
 MTK_OK, MTK_ERR_ARG, MTK_ERR_UNSUPPORTED, MTK_ERR_HIP, MTK_ERR_STATE = 0, -1, -2, -3, -4
 PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 NTAB = 15
+NOALLOC_MAX_ROWS, NOALLOC_MAX_WIDTH = 4096, 1024  # MTK_NOALLOC_MAX_ROWS / _WIDTH of include/mtk.h
 TABLE_ORDER = [
     "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_alpha", "log_1_min_alpha", "log_cumprod_alpha",
     "log_1_min_cumprod_alpha", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
@@ -35,6 +36,7 @@ _SIGS = {
     "mtk_ctx_set_math": (C.c_int, [_p, _i32]),
     "mtk_mlp_set_weights": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p]),
     "mtk_mlp_forward": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i32, _p, _i64, _i64, _i32, _p]),
+    "mtk_mlp_forward_noalloc": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i32, _p, _i64, _i64, _p]),
     "mtk_q_sample": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _u64, _u64, _p]),
     "mtk_loss_rows": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),
     "mtk_tf_score": (C.c_int, [_p, _i64, _i32, _p, _i64, _p, _i32, _p, _i32, _p, _i32, _p]),

@@ -17,6 +17,7 @@ extern "C" const char* mtk_last_error(void) { return g_err; }
 extern "C" int mtk_version(void) { return 100; }
 
 void mtk_free_mlp(mtk_ctx* c);  // mtk_mlp_f32.hip
+int mtk_noalloc_init(int device);  // mtk_mlp_f32.hip: resolves this device's copy of the static scratch array
 
 extern "C" int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K_host, const float* logK_host,
                               const double* tables_host, mtk_ctx** out) {
@@ -30,6 +31,10 @@ extern "C" int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K
     MTK_HIP(hipGetDeviceCount(&n_dev));
     if (device < 0 || device >= n_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_create: device %d of %d", device, n_dev);
     MTK_HIP(hipSetDevice(device));
+    {
+        const int rc = mtk_noalloc_init(device);  // once per device, with that device current
+        if (rc) return rc;
+    }
 
     mtk_ctx* c = new mtk_ctx();
     c->device = device;

@@ -347,6 +347,47 @@ static int forward_f32(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int6
     return forward_f32_ws(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, c->ws[0], c->ws[1], chunk, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// mtk_mlp_forward_noalloc: the exact-fp32 denoiser for callers that cannot allocate (HIP graph capture, tight serving
+// loops).  Same kernels as mtk_mlp_forward(MTK_PREC_FP32); the activation ping-pong lives in a file-scope device array
+// instead of a hipMalloc'ed workspace.  Each GPU holds its own copy of the array at its own address: the address is
+// looked up once per device (mtk_noalloc_init, called from mtk_ctx_create with that device current) and only that
+// pointer - never the array's name, which in host code is a stand-in and not a device address - reaches a kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int64_t kNoallocRows = MTK_NOALLOC_MAX_ROWS;   // 4096 (a multiple of the 128-row tile)
+constexpr int kNoallocWidth = MTK_NOALLOC_MAX_WIDTH;     // 1024
+static __device__ __align__(256) float mtk_noalloc_scratch[2 * kNoallocRows * kNoallocWidth];  // 32 MiB per GPU
+static float* g_noalloc_ptr[64] = {};
+
+int mtk_noalloc_init(int device) {  // the device must be current
+    if (device < 0 || device >= 64) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_noalloc_init: device ordinal %d above 63", device);
+    if (g_noalloc_ptr[device]) return MTK_OK;
+    float* p = nullptr;
+    MTK_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(mtk_noalloc_scratch)));
+    if (!p) MTK_FAIL(MTK_ERR_HIP, "mtk_noalloc_init: hipGetSymbolAddress returned a null address");
+    g_noalloc_ptr[device] = p;
+    return MTK_OK;
+}
+
+extern "C" int mtk_mlp_forward_noalloc(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
+                                       int t_scalar, float* out, int64_t o_rs, int64_t o_cs, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_noalloc: null context");
+    if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward_noalloc: call mtk_mlp_set_weights first");
+    if (B < 0 || !x || !out) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_noalloc: null pointer or negative B");
+    if (!t && (t_scalar < 0 || t_scalar >= c->T)) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_noalloc: t_scalar = %d outside [0, %d)", t_scalar, c->T);
+    if (B > kNoallocRows)
+        MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward_noalloc: B = %lld rows exceed the static scratch's %lld (use mtk_mlp_forward)", (long long)B, (long long)kNoallocRows);
+    if (max_pad_of(c) > kNoallocWidth)
+        MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward_noalloc: a layer %d wide exceeds the static scratch's %d columns (use mtk_mlp_forward)", max_pad_of(c), kNoallocWidth);
+    if (c->device < 0 || c->device >= 64 || !g_noalloc_ptr[c->device])
+        MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward_noalloc: the scratch address of device %d was not resolved at mtk_ctx_create", c->device);
+    if (B == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(c->device));
+    float* base = g_noalloc_ptr[c->device];
+    return forward_f32_ws(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, base, base + kNoallocRows * kNoallocWidth, kNoallocRows,
+                          (hipStream_t)stream);
+}
+
 extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
                                int t_scalar, float* out, int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: null context");

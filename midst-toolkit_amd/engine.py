@@ -106,6 +106,21 @@ class Engine:
                                              PRECISIONS[precision], self._stream()))
         return out
 
+    def mlp_forward_noalloc(self, x: torch.Tensor, t, out: torch.Tensor, x_strides=None, out_strides=None, B: int | None = None) -> torch.Tensor:
+        """mtk_mlp_forward_noalloc: the exact-fp32 denoiser through the library's static device scratch (no hipMalloc /
+        hipFree / synchronisation inside the call; B <= 4096 rows, layers <= 1024 wide).  ``out`` is caller-allocated."""
+        require_cuda(x, "mlp_forward_noalloc")
+        if B is None:
+            B = x.shape[0]
+        xs = x_strides if x_strides is not None else (x.stride(0), x.stride(1))
+        os_ = out_strides if out_strides is not None else (out.stride(0), out.stride(1))
+        tv, ts = (t, 0) if isinstance(t, torch.Tensor) else (None, int(t))
+        if tv is not None:
+            assert tv.dtype == torch.int64 and tv.is_contiguous() and tv.numel() == B
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_mlp_forward_noalloc(self._h, B, ptr(x), xs[0], xs[1], ptr(tv), ts, ptr(out), os_[0], os_[1], self._stream()))
+        return out
+
     # ------------------------------------------------------------------ loss side
     def q_sample(self, x0, t, eps, u, x_in, xi_strides, xt_idx, seed=0, row0=0):
         B = x0.shape[0]
