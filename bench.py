@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — record x timestep denoising-loss scoring throughput on MI355X.
+"""bench.py — record x timestep denoising-loss scoring throughput (+ sampled rows/s) on MI355X.
 
-Workload (BASELINE.json configs[1]): Tartan-Federer-style scoring, 100k records per GPU x timesteps,
-4x512 MLPDiffusion, 20 numeric features (shape N of SURVEY.md section 8), T = 1000, P = 1 noise draw.
-One "step" = one mtk_tf_score call over all resident records and `--nt` timesteps
-(noising -> denoiser -> per-record MSE).  Inputs are resident in HBM before the timed region.
-With N > 1 GPUs the records are sharded (weak scaling: 100k per GPU) and each step ends with the RCCL
-all-gather of the per-record score vectors.
+Headline workload (BASELINE.json configs[1]): Tartan-Federer-style scoring of 100k records per GPU x ALL 1000 timesteps,
+4x512 MLPDiffusion, 20 numeric features (shape N of SURVEY.md section 8), P = 1 noise draw.  One "step" = one
+mtk_tf_score call over all resident records and all `--nt` timesteps (noising -> denoiser -> per-record MSE, 1e8 evals,
+~150 ms).  Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the denoiser MFMA kernel);
-`cpu_baseline` times the CPU oracle (a port of the reference's op sequence in PyTorch-CPU eager) on a
-bounded sample on this box's host cores.
+N > 1 GPUs (one process per GPU, RCCL): `--mode weak` (default) keeps 100k records per GPU; `--mode strong` is
+BASELINE configs[2]: 1M records x P = 4 in total, sharded with distributed.shard_range.  Either way the only exchange is
+the gather of each rank's score block to the consumer rank 0, asynchronous and double buffered, drained inside the
+timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the headline workload (the fused
+noise + denoiser + MSE MFMA kernel); `cpu_baseline` times the CPU oracle (a port of the reference's op sequence in
+PyTorch-CPU eager) on a bounded sample on this box's host cores; `extra` carries the other half of the metric and the
+other modes, each with its own roofline fraction, measured after the timed region (N = 1 only unless noted):
+  sampling_4x512 / sampling_4x1024  sampled rows/s at T = 1000, shape M (20 numeric + 10 x 10 categorical), every rank
+  mixed_loss_shapeM                 evals/s of q_sample -> denoiser -> loss_rows at shape M with the three kernels' rates
+  parity_fp32 / parity_bf16x3       the headline workload in the two modes that carry the 1e-4 parity bar
 """
 import argparse
 import json
@@ -24,7 +31,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+DTYPE = {"bf16": "bf16", "bf16x3": "bf16 (hi+lo split operands, 3 MFMAs per product, fp32 accumulate)", "fp32": "f32"}
+TF_LAUNCH = 64  # timesteps per launch of the fused Tartan-Federer kernel (kMaxTF, mtk_mlp_bf16.hip)
 
 
 def flops_per_eval(D: int, dim_t: int, hidden: list[int]) -> int:
@@ -53,36 +63,162 @@ def cpu_baseline(params, Nn, T, seed, seconds_target=10.0):
             "sample": f"{n_rec} records x {n_t} timesteps x 1 noise draw, oracle/diffusion_oracle.tf_score (PyTorch-CPU eager), {dt:.1f} s"}
 
 
+def cpu_baseline_sampling(seed, seconds_target=6.0):
+    """The CPU oracle's reverse chain (shape M, 4x512) on a bounded sample: 1024 rows x k steps, scaled to row-steps/s."""
+    from oracle import diffusion_oracle as orc
+
+    K, Nn, T = np.array([10] * 10), 20, 1000
+    D = Nn + int(K.sum())
+    s = orc.make_schedule(T, "cosine")
+    params = orc.init_mlp_params(D, [512] * 4, seed=0)
+    g = torch.Generator().manual_seed(seed)
+    B = 1024
+    z = torch.randn((B, Nn), generator=g, dtype=torch.float64)
+    zi = torch.stack([torch.randint(0, int(k), (B,), generator=g) for k in K], 1)
+    steps = 0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds_target and steps < T:
+            t = T - 1 - steps
+            tv = torch.full((B,), t, dtype=torch.long)
+            out = orc.mlp_forward(params, orc.model_input(z.float(), zi, K), tv)
+            z = orc.gaussian_p_step(s, out[:, :Nn], z, t, torch.randn((B, Nn), generator=g, dtype=torch.float64))
+            logp = orc.q_posterior(s, orc.block_log_softmax(out[:, Nn:], K), orc.log_onehot(zi, K), tv, K)
+            zi = orc.gumbel_argmax(logp, torch.rand((B, int(K.sum())), generator=g), K)
+            steps += 1
+        dt = time.perf_counter() - t0
+    rs = B * steps / dt
+    return {"value": rs / T, "unit": "sampled rows/s at T=1000", "row_steps_per_s": rs, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{B} rows x {steps} reverse steps (denoiser + Gaussian posterior + multinomial posterior + Gumbel), oracle, {dt:.1f} s"}
+
+
 class _HostGather:
-    """Rehearsal only (MTK_BENCH_BACKEND=gloo): an asynchronous all-gather through host tensors with the
+    """Rehearsal only (MTK_BENCH_BACKEND=gloo): an asynchronous gather to rank 0 through host tensors with the
     .wait() of a torch.distributed work handle."""
 
-    def __init__(self, dist, src, dst, world):
-        self.host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
-        self.dst = dst
-        self.work = dist.all_gather(self.host, src.cpu(), async_op=True)
+    def __init__(self, dist, src, dst, world, rank):
+        self.host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)] if rank == 0 else None
+        self.dst, self.rank = dst, rank
+        self.work = dist.gather(src.cpu(), self.host, dst=0, async_op=True)
 
     def wait(self):
         self.work.wait()
-        self.dst.copy_(torch.stack(self.host))
+        if self.rank == 0:
+            for d, h in zip(self.dst, self.host):
+                d.copy_(h)
+
+
+def timeit(fn, iters=5, warm=2):
+    """Median HIP-event time (s) of fn on torch's current stream (the stream every libmtk_hip launch goes to)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    return float(np.median([s.elapsed_time(e) for s, e in ev])) * 1e-3
+
+
+def bench_sampling(mtk, dev, hidden, rows, dist, world):
+    """Sampled rows/s at T = 1000, shape M, in-kernel Philox noise (math "fast"), bf16 denoiser: every rank runs its own
+    chain over `rows` rows (no collective inside the loop); value = world x rows / max-over-ranks time."""
+    K, Nn, T = np.array([10] * 10), 20, 1000
+    D = Nn + int(K.sum())
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([hidden] * 4, 0.0))
+    net.precision = "bf16"
+    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
+    d.precision, d.rng, d.results_on_device = "bf16", "philox", True
+    d.sample(rows, torch.ones(1), seed=1)  # warm-up: packs the weights, sizes the workspaces
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    x, _ = d.sample(rows, torch.ones(1), seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    assert x.shape == (rows, Nn + len(K)) and bool(torch.isfinite(x).all())
+    # the two kernels of one reverse step, timed alone at the chain's batch size
+    eng = d.engine()
+    x_in = torch.randn((D, rows), device=dev)
+    out = torch.empty((D, rows), device=dev)
+    z = torch.randn((Nn, rows), device=dev, dtype=torch.float64)
+    zi = torch.randint(0, 10, (len(K), rows), device=dev, dtype=torch.int32)
+    t_mlp = timeit(lambda: eng.mlp_forward(x_in, 500, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows))
+    t_step = timeit(lambda: eng.p_sample_step(rows, 500, False, out, (1, rows), z, zi, None, None, x_in, (1, rows), seed=3))
+    fl = flops_per_eval(D, 128, [hidden] * 4)
+    b_step = Nn * 8 * 2 + Nn * 4 + int(K.sum()) * 4 + len(K) * 4 * 2 + D * 4  # 1,360 B per row-step (SURVEY 8d, Philox)
+    return {"sampled_rows_per_s": world * rows / dt, "row_steps_per_s": world * rows * T / dt, "rows_per_gpu": rows, "T": T, "seconds": dt,
+            "denoiser": f"4x{hidden} bf16", "rng": "philox (in-kernel)", "math": "fast", "launches": 2 * T + 2,
+            "roofline_denoiser": {"bound": "mfma", "achieved": rows * fl / t_mlp / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                  "frac": rows * fl / t_mlp / 1e12 / PEAK_TFLOPS["bf16"], "kernel_ms": t_mlp * 1e3, "flops_per_row_step": fl},
+            "roofline_step": {"bound": "hbm", "achieved": rows * b_step / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": rows * b_step / t_step / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_step * 1e3, "bytes_per_row_step": b_step},
+            "whole_loop_mfma_frac": rows * T * fl / dt / 1e12 / PEAK_TFLOPS["bf16"]}
+
+
+def bench_mixed_loss(mtk, dev, rows):
+    """Shape-M mixed_loss (q_sample -> fused bf16 denoiser -> loss_rows), in-kernel Philox noise, math "fast"."""
+    K, Nn, T = np.array([10] * 10), 20, 1000
+    C, S = len(K), int(K.sum())
+    D = Nn + S
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([512] * 4, 0.0))
+    net.precision = "bf16"
+    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
+    d.precision, d.rng = "bf16", "philox"
+    eng = d.engine()
+    g = torch.Generator().manual_seed(20250821)
+    x0 = torch.cat([torch.randn((rows, Nn), generator=g).clamp(-5.2, 5.2)] + [torch.randint(0, int(k), (rows, 1), generator=g).float() for k in K], 1).to(dev)
+    t = torch.randint(0, T, (rows,), generator=g).to(dev)
+    x_in = torch.empty((D, rows), device=dev)
+    out = torch.empty((D, rows), device=dev)
+    idx = torch.empty((C, rows), dtype=torch.int32, device=dev)
+    lm, lg = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    q = lambda: eng.q_sample(x0, t, None, None, x_in, (1, rows), idx, seed=1)  # noqa: E731
+    m = lambda: eng.mlp_forward(x_in, t, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows)  # noqa: E731
+    lo = lambda: eng.loss_rows(out, (1, rows), x0, idx, None, t, lm, lg, seed=1)  # noqa: E731
+    tq, tm, tl = timeit(q), timeit(m), timeit(lo)
+    tot = timeit(lambda: d.mixed_loss_rows(x0, timestep=t, seed=7))
+    fl = flops_per_eval(D, 128, [512] * 4)
+    b_q = (Nn + C) * 4 + 8 + D * 4 + C * 4          # 648 B per row (SURVEY 8d, Philox)
+    b_l = D * 4 + (Nn + C) * 4 + C * 4 + 8 + 8      # 656 B per row
+    hbm = lambda b, s: {"bound": "hbm", "achieved": rows * b / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rows * b / s / 1e9 / HBM_PEAK_GBS,  # noqa: E731
+                        "kernel_ms": s * 1e3, "bytes_per_row": b}
+    return {"evals_per_s": rows / tot, "rows": rows, "ms": tot * 1e3, "denoiser": "4x512 bf16 (fused)", "rng": "philox (in-kernel)", "math": "fast",
+            "roofline_q_sample": hbm(b_q, tq), "roofline_loss_rows": hbm(b_l, tl),
+            "roofline_denoiser": {"bound": "mfma", "achieved": rows * fl / tm / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                  "frac": rows * fl / tm / 1e12 / PEAK_TFLOPS["bf16"], "kernel_ms": tm * 1e3, "flops_per_eval": fl},
+            "note": "each kernel's time includes the 8 B/row pass that turns rows with an out-of-range timestep into NaN"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--records", type=int, default=100_000, help="records per GPU")
-    ap.add_argument("--nt", type=int, default=10, help="timesteps per step")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--records", type=int, default=0, help="records per GPU (weak; default 100000) or in total (strong; default 1000000)")
+    ap.add_argument("--nt", type=int, default=0, help="timesteps per step (default: all 1000 in weak mode, 100 in strong mode)")
+    ap.add_argument("--P", type=int, default=0, help="noise draws per record (default 1 weak, 4 strong)")
     ap.add_argument("--hidden", type=int, default=512)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--sample-rows", type=int, default=65536)
     a = ap.parse_args()
 
     if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr
         import faulthandler
 
-        faulthandler.dump_traceback_later(60, exit=True)
+        faulthandler.dump_traceback_later(120, exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -104,9 +240,19 @@ def main():
             dist.init_process_group(backend)
 
     import midst_toolkit_amd as mtk
-    from midst_toolkit_amd import scoring
+    from midst_toolkit_amd.distributed import shard_range
 
-    T, Nn, P, seed = 1000, 20, 1, 20250821
+    strong = a.mode == "strong"
+    T, Nn, seed = 1000, 20, 20250821
+    P = a.P or (4 if strong else 1)
+    nt = a.nt or (100 if strong else T)
+    total = a.records or (1_000_000 if strong else 100_000)
+    if strong:
+        lo, hi = shard_range(total, rank, world)
+        n_local, n_max = hi - lo, shard_range(total, 0, world)[1]
+        n_global = total
+    else:
+        lo, n_local, n_max, n_global = rank * total, total, total, total * world
     hidden = [a.hidden] * 4
     torch.manual_seed(0)
     net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(hidden, 0.0))
@@ -115,34 +261,44 @@ def main():
     diff = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev).to(dev)
     diff.precision = a.precision
 
-    g = torch.Generator().manual_seed(seed + rank)
-    x = torch.randn((a.records, Nn), generator=g).clamp(-5.2, 5.2).to(dev)  # this rank's shard, resident
+    # this rank's shard, resident; rows are a pure function of their global index (strong mode: any world size scores
+    # the same 1M records)
+    g = torch.Generator().manual_seed(seed)
+    if strong:
+        x = torch.randn((total, Nn), generator=g).clamp(-5.2, 5.2)[lo:lo + n_local].contiguous().to(dev)
+    else:
+        x = torch.randn((n_local, Nn), generator=torch.Generator().manual_seed(seed + rank)).clamp(-5.2, 5.2).to(dev)
     noise = torch.randn((P, Nn), generator=torch.Generator().manual_seed(seed)).to(dev)  # shared table
     eng = diff.engine()
-    # N > 1: the only exchange of the path is the gather of the score blocks.  It runs on RCCL's own stream while the
-    # next step's kernel computes into the other buffer pair (double buffered); a step waits, stream-side, only for
-    # the gather that last used its pair.  Every gather is drained inside the timed region.
+    # N > 1: the only exchange of the path is the gather of the score blocks to the consumer (rank 0).  It runs on RCCL's
+    # own stream while the next step's kernels compute into the other buffer (double buffered); a step waits,
+    # stream-side, only for the gather that last used its buffer.  Every gather is drained inside the timed region.
     nbuf = 2 if world > 1 else 1
-    scores = [torch.empty((a.nt, a.records, P), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    gathered = [torch.empty((world, a.nt, a.records, P), dtype=torch.float32, device=dev) for _ in range(nbuf)] if world > 1 else None
+    scores = [torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(nbuf)]  # padded to the largest shard
+    gathered = [[torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(nbuf)] if (world > 1 and rank == 0) else None
     pending = [None] * nbuf
+
+    ragged = n_local != n_max  # strong scaling with total % world != 0: score into a compact block, copy into the padded buffer
+    compact = torch.empty((nt, n_local, P), dtype=torch.float32, device=dev) if ragged else None
 
     def step(i, events=None):
         b = i % nbuf
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        ts = [(i * a.nt + k) % T for k in range(a.nt)]
+        ts = [(i * nt + k) % T for k in range(nt)]
         if events:
             events[0].record()
-        eng.tf_score(x, noise, ts, 0, a.precision, out=scores[b])
+        eng.tf_score(x, noise, ts, 0, a.precision, out=compact if ragged else scores[b])
+        if ragged:
+            scores[b][:, :n_local].copy_(compact)
         if events:
             events[1].record()
         if world > 1:
             if backend == "nccl":
-                pending[b] = dist.all_gather_into_tensor(gathered[b], scores[b], async_op=True)
+                pending[b] = dist.gather(scores[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
             else:  # gloo rehearsal of the control flow: staged through host tensors
-                pending[b] = _HostGather(dist, scores[b], gathered[b], world)
+                pending[b] = _HostGather(dist, scores[b], gathered[b] if rank == 0 else None, world, rank)
 
     def barrier():
         for b in range(nbuf):
@@ -163,44 +319,275 @@ def main():
         step(a.warmup + i, ev[i])
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived in rank order
+    if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived at the consumer, in rank order
         last = (a.warmup + a.steps - 1) % nbuf
-        assert torch.equal(gathered[last][rank], scores[last])
-        mine = torch.stack([t.flatten()[:4] for t in gathered[last]])
-        ref = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(ref, mine)
-        assert all(torch.equal(r, mine) for r in ref)
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        mine = scores[last].flatten()[:4].to(cdev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        if rank == 0:
+            assert torch.equal(gathered[last][0], scores[last])
+            for r in range(world):
+                assert torch.equal(gathered[last][r].flatten()[:4].cpu(), every[r].cpu()), r
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))  # HIP events on the launch stream
+    assert x.shape == (rows, Nn + len(K)) and bool(torch.isfinite(x).all())
+    # the two kernels of one reverse step, timed alone at the chain's batch size
+    eng = d.engine()
+    x_in = torch.randn((D, rows), device=dev)
+    out = torch.empty((D, rows), device=dev)
+    z = torch.randn((Nn, rows), device=dev, dtype=torch.float64)
+    zi = torch.randint(0, 10, (len(K), rows), device=dev, dtype=torch.int32)
+    t_mlp = timeit(lambda: eng.mlp_forward(x_in, 500, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows))
+    t_step = timeit(lambda: eng.p_sample_step(rows, 500, False, out, (1, rows), z, zi, None, None, x_in, (1, rows), seed=3))
+    fl = flops_per_eval(D, 128, [hidden] * 4)
+    b_step = Nn * 8 * 2 + Nn * 4 + int(K.sum()) * 4 + len(K) * 4 * 2 + D * 4  # 1,360 B per row-step (Philox)
+    return {"sampled_rows_per_s": world * rows / dt, "row_steps_per_s": world * rows * T / dt, "rows_per_gpu": rows, "T": T, "seconds": dt,
+            "denoiser": f"4x{hidden} bf16", "rng": "philox (in-kernel)", "math": "fast", "launches": 2 * T + 2,
+            "roofline_denoiser": {"bound": "mfma", "achieved": rows * fl / t_mlp / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                  "frac": rows * fl / t_mlp / 1e12 / PEAK_TFLOPS["bf16"], "kernel_ms": t_mlp * 1e3, "flops_per_row_step": fl},
+            "roofline_step": {"bound": "hbm", "achieved": rows * b_step / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": rows * b_step / t_step / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_step * 1e3, "bytes_per_row_step": b_step},
+            "whole_loop_mfma_frac": rows * T * fl / dt / 1e12 / PEAK_TFLOPS["bf16"]}
 
+
+def bench_mixed_loss(mtk, dev, rows):
+    """Shape-M mixed_loss (q_sample -> fused bf16 denoiser -> loss_rows), in-kernel Philox noise, math "fast"."""
+    K, Nn, T = np.array([10] * 10), 20, 1000
+    C, S = len(K), int(K.sum())
+    D = Nn + S
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([512] * 4, 0.0))
+    net.precision = "bf16"
+    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
+    d.precision, d.rng = "bf16", "philox"
+    eng = d.engine()
+    g = torch.Generator().manual_seed(20250821)
+    x0 = torch.cat([torch.randn((rows, Nn), generator=g).clamp(-5.2, 5.2)] + [torch.randint(0, int(k), (rows, 1), generator=g).float() for k in K], 1).to(dev)
+    t = torch.randint(0, T, (rows,), generator=g).to(dev)
+    x_in = torch.empty((D, rows), device=dev)
+    out = torch.empty((D, rows), device=dev)
+    idx = torch.empty((C, rows), dtype=torch.int32, device=dev)
+    lm, lg = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    q = lambda: eng.q_sample(x0, t, None, None, x_in, (1, rows), idx, seed=1)  # noqa: E731
+    m = lambda: eng.mlp_forward(x_in, t, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows)  # noqa: E731
+    lo = lambda: eng.loss_rows(out, (1, rows), x0, idx, None, t, lm, lg, seed=1)  # noqa: E731
+    tq, tm, tl = timeit(q), timeit(m), timeit(lo)
+    tot = timeit(lambda: d.mixed_loss_rows(x0, timestep=t, seed=7))
+    fl = flops_per_eval(D, 128, [512] * 4)
+    b_q = (Nn + C) * 4 + 8 + D * 4 + C * 4          # 648 B per row (SURVEY 8d, Philox)
+    b_l = D * 4 + (Nn + C) * 4 + C * 4 + 8 + 8      # 656 B per row
+    hbm = lambda b, s: {"bound": "hbm", "achieved": rows * b / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rows * b / s / 1e9 / HBM_PEAK_GBS,  # noqa: E731
+                        "kernel_ms": s * 1e3, "bytes_per_row": b}
+    return {"evals_per_s": rows / tot, "rows": rows, "ms": tot * 1e3, "denoiser": "4x512 bf16 (fused)", "rng": "philox (in-kernel)", "math": "fast",
+            "roofline_q_sample": hbm(b_q, tq), "roofline_loss_rows": hbm(b_l, tl),
+            "roofline_denoiser": {"bound": "mfma", "achieved": rows * fl / tm / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                  "frac": rows * fl / tm / 1e12 / PEAK_TFLOPS["bf16"], "kernel_ms": tm * 1e3, "flops_per_eval": fl},
+            "note": "each kernel's time includes the 8 B/row pass that turns rows with an out-of-range timestep into NaN"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--records", type=int, default=0, help="records per GPU (weak; default 100000) or in total (strong; default 1000000)")
+    ap.add_argument("--nt", type=int, default=0, help="timesteps per step (default: all 1000 in weak mode, 100 in strong mode)")
+    ap.add_argument("--P", type=int, default=0, help="noise draws per record (default 1 weak, 4 strong)")
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--sample-rows", type=int, default=65536)
+    a = ap.parse_args()
+
+    if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr
+        import faulthandler
+
+        faulthandler.dump_traceback_later(120, exit=True)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    # MTK_BENCH_BACKEND=gloo rehearses the N > 1 control flow with several ranks on one card (RCCL refuses that)
+    backend = os.environ.get("MTK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    import midst_toolkit_amd as mtk
+    from midst_toolkit_amd.distributed import shard_range
+
+    strong = a.mode == "strong"
+    T, Nn, seed = 1000, 20, 20250821
+    P = a.P or (4 if strong else 1)
+    nt = a.nt or (100 if strong else T)
+    total = a.records or (1_000_000 if strong else 100_000)
+    if strong:
+        lo, hi = shard_range(total, rank, world)
+        n_local, n_max = hi - lo, shard_range(total, 0, world)[1]
+        n_global = total
+    else:
+        lo, n_local, n_max, n_global = rank * total, total, total, total * world
+    hidden = [a.hidden] * 4
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(hidden, 0.0))
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net.precision = a.precision
+    diff = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev).to(dev)
+    diff.precision = a.precision
+
+    # this rank's shard, resident; rows are a pure function of their global index (strong mode: any world size scores
+    # the same 1M records)
+    g = torch.Generator().manual_seed(seed)
+    if strong:
+        x = torch.randn((total, Nn), generator=g).clamp(-5.2, 5.2)[lo:lo + n_local].contiguous().to(dev)
+    else:
+        x = torch.randn((n_local, Nn), generator=torch.Generator().manual_seed(seed + rank)).clamp(-5.2, 5.2).to(dev)
+    noise = torch.randn((P, Nn), generator=torch.Generator().manual_seed(seed)).to(dev)  # shared table
+    eng = diff.engine()
+    # N > 1: the only exchange of the path is the gather of the score blocks to the consumer (rank 0).  It runs on RCCL's
+    # own stream while the next step's kernels compute into the other buffer (double buffered); a step waits,
+    # stream-side, only for the gather that last used its buffer.  Every gather is drained inside the timed region.
+    nbuf = 2 if world > 1 else 1
+    scores = [torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(nbuf)]  # padded to the largest shard
+    gathered = [[torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(nbuf)] if (world > 1 and rank == 0) else None
+    pending = [None] * nbuf
+
+    ragged = n_local != n_max  # strong scaling with total % world != 0: score into a compact block, copy into the padded buffer
+    compact = torch.empty((nt, n_local, P), dtype=torch.float32, device=dev) if ragged else None
+
+    def step(i, events=None):
+        b = i % nbuf
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        ts = [(i * nt + k) % T for k in range(nt)]
+        if events:
+            events[0].record()
+        eng.tf_score(x, noise, ts, 0, a.precision, out=compact if ragged else scores[b])
+        if ragged:
+            scores[b][:, :n_local].copy_(compact)
+        if events:
+            events[1].record()
+        if world > 1:
+            if backend == "nccl":
+                pending[b] = dist.gather(scores[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+            else:  # gloo rehearsal of the control flow: staged through host tensors
+                pending[b] = _HostGather(dist, scores[b], gathered[b] if rank == 0 else None, world, rank)
+
+    def barrier():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i, ev[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived at the consumer, in rank order
+        last = (a.warmup + a.steps - 1) % nbuf
+        mine = scores[last].flatten()[:4].cpu()
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine) if backend != "nccl" else dist.all_gather(every := [t.to(dev) for t in every], mine.to(dev))
+        if rank == 0:
+            assert torch.equal(gathered[last][0], scores[last])
+            for r in range(world):
+                assert torch.equal(gathered[last][r].flatten()[:4].cpu(), every[r].cpu()), r
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    step_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))  # HIP events on the launch stream, around one mtk_tf_score call
+
+    fused = a.precision == "bf16" and a.hidden == 512
+    launches = (nt + TF_LAUNCH - 1) // TF_LAUNCH if fused else None
+    kern_ms = step_ms / launches if fused else step_ms
     # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes of this same configuration
     traffic = None
-    pmc = os.path.join(ROOT, "benchmarks", "pmc_fused.json")  # copy of profiles/r1_pmc_fused.json that travels to the GPU box
-    if a.precision == "bf16" and a.records == 100_000 and a.nt == 10 and a.hidden == 512 and os.path.exists(pmc):
+    pmc = os.path.join(ROOT, "benchmarks", "pmc_fused.json")  # copy of profiles/r2_pmc_fused.json that travels to the GPU box
+    if fused and n_local == 100_000 and nt == 1000 and P == 1 and os.path.exists(pmc):
         with open(pmc) as f:
             rec = json.load(f)
-        traffic = rec["fetch_bytes_per_launch_corrected_x2"] + rec["write_bytes_per_launch"]
-    evals_step = a.records * a.nt * P
+        if rec.get("timesteps_per_step") == nt:
+            traffic = rec["fetch_bytes_per_launch_corrected_x2"] + rec["write_bytes_per_launch"]
+    evals_step = n_local * nt * P
     fl = flops_per_eval(Nn, 128, hidden)
-    achieved = evals_step * fl / (kern_ms * 1e-3) / 1e12
+    achieved = evals_step * fl / (step_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[a.precision]
+    kernel_name = {"bf16": "k_fused<512,1,1>: fused Tartan-Federer kernel (noising + denoiser + MSE), one launch per 64 timesteps" if fused
+                   else "layered bf16 MFMA denoiser between noising and MSE kernels (whole step)",
+                   "bf16x3": "layered split-bf16 MFMA denoiser (k_gemm_bf16<SPLIT>) between noising and MSE kernels (whole step)",
+                   "fp32": "layered f32-MFMA denoiser (k_gemm_f32) between noising and MSE kernels (whole step)"}[a.precision]
+    if strong:
+        workload = (f"Loss-based MIA scoring (BASELINE configs[2]): {total} records x {nt} timesteps/step x P={P} noise draws in total, sharded over "
+                    f"{world} GPU(s) with shard_range, score blocks gathered to rank 0")
+    else:
+        workload = (f"Tartan-Federer denoising-loss scoring (BASELINE configs[1]): {total} records/GPU x {nt} timesteps/step (T=1000: "
+                    f"{'every timestep' if nt == T else 'a slice'}), P={P}")
+    workload += (f", 20 numeric features, 4x{a.hidden} MLPDiffusion, precision {a.precision}; injected shared [P,Nn] noise table (TF semantics: no "
+                 "in-kernel RNG on this path), math: reference formulas (noising is one fp32 FMA pair); random-init weights")
     out = {
-        "metric": "record·timestep loss evals/sec", "value": world * evals_step * a.steps / dt, "unit": "evals/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if a.precision == "bf16" else "f32", "data": "synthetic",
-        "config": {"workload": f"Tartan-Federer denoising-loss scoring (BASELINE configs[1]): {a.records} records/GPU x {a.nt} timesteps/step, "
-                               f"P=1, 20 numeric features, 4x{a.hidden} MLPDiffusion, T=1000; random-init weights",
-                   "records_per_gpu": a.records, "timesteps_per_step": a.nt, "hidden": a.hidden, "sharding": f"records/{world}"},
+        "metric": "record·timestep loss evals/sec (node) + sampled rows/sec, T=1000", "value": (n_global if strong else world * n_local) * nt * P * a.steps / dt,
+        "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": DTYPE[a.precision], "data": "synthetic",
+        "config": {"workload": workload, "records_per_gpu": n_local, "timesteps_per_step": nt, "noise_draws": P, "hidden": a.hidden,
+                   "sharding": f"records/{world}", "evals_per_step": (n_global if strong else world * n_local) * nt * P},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                     "kernel": "fused tf-score kernel (noise + denoiser + MSE)" if a.precision == "bf16" else "layered f32-MFMA denoiser (whole step)",
-                     "flops_per_eval": fl, "kernel_ms": kern_ms},
+                     "kernel": kernel_name, "flops_per_eval": fl, "kernel_ms": kern_ms, "launches_per_step": launches,
+                     "flops_per_launch": evals_step * fl / launches if fused else evals_step * fl},
     }
+
+    extras = {}
+    if not a.no_extras and not strong:
+        # the other half of the metric, on every rank (independent chains, no collective in the loop)
+        extras["sampling_4x512"] = bench_sampling(mtk, dev, 512, a.sample_rows, dist, world)
+        extras["sampling_4x1024"] = bench_sampling(mtk, dev, 1024, a.sample_rows, dist, world)
+        out["sampled_rows_per_s"] = extras["sampling_4x1024"]["sampled_rows_per_s"]  # BASELINE configs[3]: 4x1024, shape M, T = 1000
+        out["sampled_rows_per_s_4x512"] = extras["sampling_4x512"]["sampled_rows_per_s"]
+    if not a.no_extras and world == 1 and not strong:
+        extras["mixed_loss_shapeM"] = bench_mixed_loss(mtk, dev, 1 << 20)
+        for prec, nt_p in (("fp32", 10), ("bf16x3", 20)):  # the modes that carry the <= 1e-4 parity bar, same records
+            if prec == a.precision:
+                continue
+            ts = list(range(0, T, T // nt_p))[:nt_p]
+            buf = torch.empty((nt_p, n_local, P), dtype=torch.float32, device=dev)
+            secs = timeit(lambda: eng.tf_score(x, noise, ts, 0, prec, out=buf), iters=3, warm=1)
+            tf = n_local * nt_p * P * fl / secs / 1e12
+            extras[f"parity_{prec}"] = {"evals_per_s": n_local * nt_p * P / secs, "records": n_local, "timesteps": nt_p, "ms": secs * 1e3,
+                                        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                                                     "frac": tf / PEAK_TFLOPS[prec], "note": "bf16x3 issues 3 MFMAs per product: frac counts algorithmic FLOPs"},
+                                        "parity": "<= 1e-4 relative vs the reference (tests/test_gpu_parity.py)"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params, Nn, T, seed)
+        if extras:
+            extras["cpu_baseline_sampling"] = cpu_baseline_sampling(seed)
+    if extras:
+        out["extra"] = extras
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1 << 20)
     ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--hbm-only", action="store_true", help="only the three HBM-bound diffusion kernels, fast math (PMC passes)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B, Nn, K, T = a.rows, 20, np.array([10] * 10), 1000
@@ -60,7 +61,7 @@ def main():
         print(json.dumps({"kernel": name, "rows": B, "ms": secs * 1e3, "bytes_per_row": bytes_per_row, "GB/s": gbs,
                           "frac_of_8TBs": gbs / HBM_PEAK, "rows_per_s": B / secs, "note": note}), flush=True)
 
-    for math in ("fast", "reference"):
+    for math in (("fast",) if a.hbm_only else ("fast", "reference")):
       eng.set_math(math)
       tag = f"Philox, math={math}"
       # q_sample, Philox noise: read x0 (Nn + C floats) + t; write model input D floats + C idx
@@ -75,6 +76,8 @@ def main():
       b_s = Nn * 8 * 2 + Nn * 4 + S * 4 + C * 4 * 2 + D * 4
       emit(f"mtk_p_sample_step ({tag})", timeit(lambda: eng.p_sample_step(B, 500, False, out, (1, B), z, zi, None, None, x_in, (1, B), seed=1)), b_s)
     eng.set_math("fast")
+    if a.hbm_only:
+        return
     # denoiser alone, shape M
     for prec in ("bf16", "fp32"):
         secs = timeit(lambda: eng.mlp_forward(x_in, t, out=out, precision=prec, x_strides=(1, B), out_strides=(1, B), B=B), iters=5)

@@ -23,20 +23,43 @@ def _last_json(text):
 
 
 def test_bench_line_single_gpu():
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--records", "8192", "--nt", "2", "--no-cpu-baseline"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--records", "8192", "--nt", "70", "--no-cpu-baseline",
+                        "--sample-rows", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = _last_json(r.stdout)
     assert KEYS <= set(out) and out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
-    assert "workload" in out["config"]
+    assert out["roofline"]["launches_per_step"] == 2  # 70 timesteps = one launch of 64 + one of 6
+    assert "workload" in out["config"] and "math" in out["config"]["workload"]
+    # the other half of the metric and the other modes ride in the same line, each with its own roofline fraction
+    assert out["sampled_rows_per_s"] > 0 and out["sampled_rows_per_s_4x512"] > 0
+    ex = out["extra"]
+    for k in ("sampling_4x512", "sampling_4x1024"):
+        assert ex[k]["T"] == 1000 and 0 < ex[k]["roofline_denoiser"]["frac"] < 1 and 0 < ex[k]["roofline_step"]["frac"] < 1
+    ml = ex["mixed_loss_shapeM"]
+    assert ml["evals_per_s"] > 0 and all(0 < ml[k]["frac"] < 1 for k in ("roofline_q_sample", "roofline_loss_rows", "roofline_denoiser"))
+    assert ex["parity_fp32"]["evals_per_s"] > 0 and ex["parity_bf16x3"]["evals_per_s"] > ex["parity_fp32"]["evals_per_s"]
 
 
 def test_bench_two_rank_rehearsal():
     env = dict(os.environ, MTK_BENCH_BACKEND="gloo", MTK_BENCH_CHECK="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "2"],
+                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "2", "--sample-rows", "1024"],
                        cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["sampled_rows_per_s"] > 0  # every rank ran its own chain
+
+
+def test_bench_two_rank_strong_scaling_rehearsal():
+    """BASELINE configs[2] shape of the loop: a fixed record set split with shard_range (ragged: 8191 records over two ranks),
+    P = 4, blocks gathered to rank 0."""
+    env = dict(os.environ, MTK_BENCH_BACKEND="gloo", MTK_BENCH_CHECK="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--mode", "strong", "--records", "8191",
+                        "--nt", "3"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["noise_draws"] == 4
+    assert out["config"]["evals_per_step"] == 8191 * 3 * 4

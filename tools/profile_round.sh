@@ -1,0 +1,51 @@
+#!/bin/bash
+# tools/profile_round.sh <tag>: on the GPU box (through gpurun), the rocprofv3 evidence of a round:
+#   1. --kernel-trace --stats of the default `python3 bench.py` command            -> gpurun_out/<tag>/bench_*_kernel_stats.csv + bench.json
+#   2. separate --pmc passes (FETCH_SIZE; WRITE_SIZE) of the same command, short    -> gpurun_out/<tag>/pmc_bench_{fetch,write}/
+#   3. --kernel-trace --stats of benchmarks/bench_train_sample.py --train-only      -> gpurun_out/<tag>/train_*_kernel_stats.csv
+#   4. --pmc passes of benchmarks/bench_kernels.py (the three HBM kernels)          -> gpurun_out/<tag>/pmc_kernels_{fetch,write}/
+# Each step runs under its own time limit; a step that times out or aborts ends the script.
+set -uo pipefail
+tag=${1:-prof}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+cd /tmp
+step() {  # name seconds command...
+  local name=$1 secs=$2; shift 2
+  echo "== $name"
+  timeout -s KILL "$secs" "$@" > "$out/$name.log" 2>&1
+  local rc=$?
+  echo "   rc=$rc $(tail -n 1 "$out/$name.log" | cut -c1-200)"
+  case $rc in 124|137|134|139) echo "!! $name ended with $rc: stopping"; exit $rc;; esac
+}
+step bench_stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench_stats" -o bench -- python3 "$root/bench.py"
+grep '^{' "$out/bench_stats.log" | tail -n 1 > "$out/bench.json"
+step pmc_bench_fetch 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_bench_fetch" -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+step pmc_bench_write 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_bench_write" -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+step train_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_stats" -o train -- python3 "$root/benchmarks/bench_train_sample.py" --train-only
+step kernels_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kernels_stats" -o kernels -- python3 "$root/benchmarks/bench_kernels.py"
+step pmc_kernels_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_kernels_fetch" -o pmc -- python3 "$root/benchmarks/bench_kernels.py" --hbm-only
+step pmc_kernels_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_kernels_write" -o pmc -- python3 "$root/benchmarks/bench_kernels.py" --hbm-only
+# summaries: per kernel, launches and mean counter value
+python3 - "$out" <<'PY'
+import collections, csv, glob, json, os, sys
+out = sys.argv[1]
+res = {}
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:90]
+            if "at::" in k or "rocclr" in k or "elementwise" in k:
+                continue
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    res[os.path.basename(d)] = {k: {"launches": len(n[k]), **{c: v / len(n[k]) for c, v in cs.items()}} for k, cs in acc.items()}
+json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(res)[:3000])
+PY
+for f in $(find "$out" -name "*kernel_stats.csv"); do cp "$f" "$out/$(basename $(dirname $(dirname $f)))_$(basename $f)" 2>/dev/null || true; done
+ls "$out"
