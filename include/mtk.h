@@ -250,6 +250,16 @@ int mtk_train_attach(mtk_ctx* ctx, float* state, const float* freqs_host, mtk_st
 int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
                    const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
                    uint64_t row0, mtk_stream stream);
+/* The two halves of mtk_train_step as separate calls: the autograd seam of the drop-in's mixed_loss (TRAINER:89-91 calls
+ * mixed_loss and then .backward() on the sum of its two scalars; attacks/ensemble/clavaddpm_fine_tuning.py does the same).
+ * mtk_train_forward = noising + denoiser forward with every activation kept + per-record losses.  mtk_train_backward fills
+ * image 1 with d[w_multi * sum_rows loss_multi + w_gauss * sum_rows loss_gauss] / d weights from the activations the LAST
+ * mtk_train_forward on this context left behind; x0 / t / eps / seed / row0 must be that call's (B is checked).  With
+ * w_multi = w_gauss = 1 / B this is the gradient of (mean loss_multi + mean loss_gauss), what loss.backward() produces. */
+int mtk_train_forward(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u,
+                      float* loss_multi, float* loss_gauss, uint64_t seed, uint64_t row0, mtk_stream stream);
+int mtk_train_backward(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, double w_multi,
+                       double w_gauss, uint64_t seed, uint64_t row0, mtk_stream stream);
 /* TRAINER:92 + :133: torch.optim.AdamW.step() (decoupled decay, bias correction, step is 1-based) on images
  * 0/2/3 from image 1, then EMA image 4 <- ema_rate * image 4 + (1 - ema_rate) * image 0, then the
  * time-embedding table is rebuilt from the new weights.  The caller owns the learning-rate anneal

@@ -64,6 +64,7 @@ struct TrainState {
     int Tpad = 0;
     // activations for `cap` rows (a multiple of 128)
     int64_t cap = 0;
+    int64_t fwd_rows = 0;          // rows of the last forward phase (mtk_train_backward must match it)
     float* xin = nullptr;          // [round_up(D,128)][cap] column-major model input
     int32_t* xt_idx = nullptr;     // [C][cap]
     std::vector<float*> act;       // act[0] = proj output, act[i] = block i output, row-major [cap][out_pad]

@@ -1261,10 +1261,11 @@ int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0,
 // internal (mtk_train.hip): per-record losses and d(mean loss)/d(out); out / dout column-major [D][ld]
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
-                         float* dout, double inv_global_batch, uint64_t seed, uint64_t row0, hipStream_t stream) {
+                         float* dout, double w_multi, double w_gauss, uint64_t seed, uint64_t row0, hipStream_t stream) {
+    // d(w_gauss * sum_rows loss_gauss + w_multi * sum_rows loss_multi) / d out
     LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
-                   ctx->Nn > 0 ? (float)(2.0 * inv_global_batch / ctx->Nn) : 0.0f,
-                   ctx->C > 0 ? (float)((double)ctx->T * inv_global_batch / ctx->C) : 0.0f, seed, row0};
+                   ctx->Nn > 0 ? (float)(2.0 * w_gauss / ctx->Nn) : 0.0f,
+                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0};
     int64_t grid = (B + 63) / 64;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(ctx->fast_math ? k_loss_grad<true> : k_loss_grad<false>, dim3((unsigned)grid), dim3(64 * kLgWaves), lds_bytes(ctx, false), stream, a);

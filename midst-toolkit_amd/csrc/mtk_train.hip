@@ -19,7 +19,7 @@
 
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
-                         float* dout, double inv_global_batch, uint64_t seed, uint64_t row0, hipStream_t stream);  // mtk_diffusion.hip
+                         float* dout, double w_multi, double w_gauss, uint64_t seed, uint64_t row0, hipStream_t stream);  // mtk_diffusion.hip
 
 namespace {
 
@@ -476,9 +476,13 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     return MTK_OK;
 }
 
-extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
-                              const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
-                              uint64_t row0, mtk_stream stream) {
+// One training iteration's device work, in two phases that may be issued by separate calls (the autograd seam of the
+// drop-in's mixed_loss): FORWARD = noising, denoiser forward with every activation kept, per-record losses;
+// BACKWARD = d[(w_multi sum_rows loss_multi + w_gauss sum_rows loss_gauss)] / d weights into image 1, from the
+// activations the last FORWARD on this context left behind (x0 / t / eps / seed / row0 must be that call's).
+static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u,
+                        double w_multi, double w_gauss, float* loss_multi, float* loss_gauss, uint64_t seed, uint64_t row0,
+                        bool do_fwd, bool do_bwd, mtk_stream stream) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null context");
     if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_step: call mtk_train_attach first");
     if (B <= 0 || !x0 || !t) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null pointer or B <= 0");
@@ -489,16 +493,17 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
     TrainState& tr = c->train;
     const int64_t Mpad = (B + TM - 1) / TM * TM;
     int rc;
+    if (do_bwd && !do_fwd && (Mpad > tr.cap || tr.fwd_rows != B))
+        MTK_FAIL(MTK_ERR_STATE, "mtk_train_backward: the last mtk_train_forward on this context was for %lld rows, not %lld", (long long)tr.fwd_rows, (long long)B);
     if ((rc = ensure_acts(c, Mpad, s))) return rc;
     const int64_t ld = tr.cap;  // leading dimension of the column-major buffers
     const int Dp = round_up(c->D, 128);
     const size_t n = tr.n_img;
     float* grads = tr.state + n;
 
-    MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
+    if (do_fwd) {
+    tr.fwd_rows = B;
     MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * ld, s));
-    MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
-    MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
 
     // ---- forward, activations kept
     // xt_idx is addressed [C][B] by the kernels (row stride B)
@@ -527,9 +532,16 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
         g.C = tr.out; g.c_rs = 1; g.c_cs = ld; g.bias = l.b32;
         if ((rc = launch<false, false>(g, s))) return rc;
     }
+    }
+    if (!do_bwd) {  // losses only (the gradient scratch it also fills is rewritten by the backward phase)
+        return mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout, 0.0, 0.0, seed, row0, s);
+    }
+    MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
+    MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
+    MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
     // ---- loss and d loss / d out (column-major, rows >= B and features >= D stay zero)
     if ((rc = mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout,
-                                   inv_global_batch, seed, row0, s)))
+                                   w_multi, w_gauss, seed, row0, s)))
         return rc;
 
     // ---- backward
@@ -604,6 +616,22 @@ extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0
     }
     MTK_HIP(hipGetLastError());
     return MTK_OK;
+}
+
+extern "C" int mtk_train_step(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                              const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
+                              uint64_t row0, mtk_stream stream) {
+    return train_phases(c, B, x0, x0_ld, t, eps, u, inv_global_batch, inv_global_batch, loss_multi, loss_gauss, seed, row0, true, true, stream);
+}
+
+extern "C" int mtk_train_forward(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                                 const float* u, float* loss_multi, float* loss_gauss, uint64_t seed, uint64_t row0, mtk_stream stream) {
+    return train_phases(c, B, x0, x0_ld, t, eps, u, 0.0, 0.0, loss_multi, loss_gauss, seed, row0, true, false, stream);
+}
+
+extern "C" int mtk_train_backward(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                                  double w_multi, double w_gauss, uint64_t seed, uint64_t row0, mtk_stream stream) {
+    return train_phases(c, B, x0, x0_ld, t, eps, nullptr, w_multi, w_gauss, nullptr, nullptr, seed, row0, false, true, stream);
 }
 
 extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, double beta1, double beta2, double eps,

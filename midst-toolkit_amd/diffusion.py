@@ -49,6 +49,37 @@ def _default_device() -> torch.device:
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+class _MixedLossFunction(torch.autograd.Function):
+    """The autograd seam of ``mixed_loss`` (TRAINER:89-91: ``loss = lm + lg; loss.backward()``): forward is
+    mtk_train_forward (noising, denoiser forward with the activations kept on the device context, per-record losses),
+    backward is mtk_train_backward into the context's gradient image, handed to autograd as the parameters' gradients.
+    fp32 MFMA arithmetic, like ClavaDDPMTrainer's fused iteration (same kernels)."""
+
+    @staticmethod
+    def forward(ctx, diffusion, x0, t, eps, u, seed, *params):
+        eng = diffusion._autograd_engine()
+        B, dev = x0.shape[0], x0.device
+        lm = torch.empty((B,), dtype=torch.float32, device=dev) if eng.C > 0 else None
+        lg = torch.empty((B,), dtype=torch.float32, device=dev) if eng.Nn > 0 else None
+        ctx.token = eng.train_forward(x0, t, eps, u, lm, lg, seed=seed)
+        ctx.eng, ctx.net, ctx.seed, ctx.B = eng, diffusion._denoise_fn, seed, B
+        ctx.inputs = (x0, t, eps)
+        ctx.needs = [p.requires_grad for p in params]
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        return (lm.mean() if lm is not None else zero), (lg.mean() if lg is not None else zero)
+
+    @staticmethod
+    def backward(ctx, g_multi, g_gauss):
+        x0, t, eps = ctx.inputs
+        w_multi = float(g_multi) / ctx.B if g_multi is not None else 0.0
+        w_gauss = float(g_gauss) / ctx.B if g_gauss is not None else 0.0
+        ctx.eng.train_backward(ctx.token, x0, t, eps, w_multi, w_gauss, seed=ctx.seed)
+        bufs = [(torch.empty_like(W.data), torch.empty_like(b.data)) for W, b in ctx.net._weights()]
+        ctx.eng.train_export("grads", bufs)
+        flat = [g for pair in bufs for g in pair]
+        return (None,) * 6 + tuple(g if need else None for g, need in zip(flat, ctx.needs))
+
+
 class GaussianMultinomialDiffusion(torch.nn.Module):
     def __init__(
         self,
@@ -139,6 +170,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             if hasattr(self._denoise_fn, "attach_engine"):
                 self._denoise_fn.attach_engine(self._engine)
         if hasattr(self._denoise_fn, "sync_weights"):
+            if getattr(self._engine, "_train_state", None) is not None and self.precision != "fp32" and not getattr(self, "_keep_training_image", False):
+                self._denoise_fn._synced_key = None  # the packed bf16 images do not follow a training image: detach and re-pack
             self._denoise_fn.sync_weights()
         self._engine.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
         return self._engine
@@ -245,12 +278,92 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         """GMD:1013: (mean multinomial loss / C, mean Gaussian loss).  ``outputs['y']`` is accepted
         and ignored like the reference's denoiser ignores it (MODEL:610)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "mixed_loss does not build an autograd graph: train with midst_toolkit_amd.trainer.ClavaDDPMTrainer "
-                "(HIP forward + backward + AdamW), or call under torch.no_grad() for loss evaluation / scoring"
-            )
+            return self._mixed_loss_autograd(features)
         lm, lg = self.mixed_loss_rows(features)
         return lm.mean(), lg.mean()
+
+    # ------------------------------------------------------------------ differentiable entry point (TRAINER:89-91)
+    def _autograd_engine(self) -> Engine:
+        """The context with a training image attached and image 0 equal to the module's current parameters."""
+        from .model import timestep_frequencies
+
+        net = self._denoise_fn
+        if self._engine is None or self._engine.device != self.alphas.device:
+            self.engine()
+        eng = self._engine
+        key = tuple((p.data_ptr(), p._version) for wb in net._weights() for p in wb)
+        if getattr(eng, "_train_state", None) is None:
+            net.sync_weights()  # layer shapes and current weights into the context, then the [5, n] image on top
+            eng.train_attach(timestep_frequencies(net.timestep_dimension))
+            self._ag_key = key
+        elif key != getattr(self, "_ag_key", None):  # an optimizer step (or a load) changed the parameters
+            eng.train_import("weights", [(W.data, b.data) for W, b in net._weights()])
+            self._ag_key = key
+        return eng
+
+    def _mixed_loss_autograd(self, features: Tensor) -> tuple[Tensor, Tensor]:
+        """``mixed_loss`` with an autograd graph: ``(lm + lg).backward()`` fills ``param.grad`` of the denoiser's 12 tensors
+        from the HIP backward pass, so the reference's own ``ClavaDDPMTrainer`` loop (zero_grad, mixed_loss, backward,
+        ``torch.optim.AdamW.step``; TRAINER:70-94) and ``clavaddpm_fine_tuning.py`` run against the drop-in unchanged.
+        One differentiable forward is outstanding per model at a time (its activations live on the device context)."""
+        if not features.is_cuda:
+            raise RuntimeError("mixed_loss: midst_toolkit_amd has no CPU path; move the model and batch to the MI355X")
+        if getattr(self.gaussian_loss_type, "value", "mse") != "mse":
+            raise NotImplementedError("the HIP backward pass differentiates the MSE Gaussian loss only (every shipped config)")
+        x0 = features.float().contiguous()
+        B, dev = x0.shape[0], x0.device
+        seed = 0
+        if self.rng == "torch":
+            t, eps, u = self._draw_loss_noise(x0)
+        else:
+            t = torch.randint(0, self.num_timesteps, (B,), device=dev).long()
+            eps = u = None
+            seed = int(torch.randint(1, 2**62, (1,)).item())
+        t = t.to(dev, torch.int64).contiguous()
+        eps = eps.float().contiguous() if eps is not None and eps.numel() else None
+        u = u.float().contiguous() if u is not None and u.numel() else None
+        net = self._denoise_fn
+        eng = self._autograd_engine()
+        eng.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
+        params = [p for wb in net._weights() for p in wb]
+        lm, lg = _MixedLossFunction.apply(self, x0, t, eps, u, seed, *params)
+        zero = torch.zeros((1,)).float().mean()  # GMD:1047-1048, 1068: an absent side is the mean of a CPU zeros((1,)), 0-dim
+        return (lm if eng.C > 0 else zero), (lg if eng.Nn > 0 else zero)
+
+    @classmethod
+    def from_reference_state(cls, state_dict: dict[str, Tensor], ctor_args: dict[str, Any], device: torch.device | None = None) -> "GaussianMultinomialDiffusion":
+        """Model ingestion without unpickling reference classes: ``state_dict`` is the reference object's
+        ``state_dict()`` (26 entries: ``_denoise_fn.*`` parameters + the 14 schedule buffers; extra or missing buffers are
+        checked by a strict load) and ``ctor_args`` the keyword arguments of GMD:156-168 except ``denoise_fn`` -
+        ``num_classes``, ``num_numerical_features`` and optionally ``num_timesteps``, ``gaussian_loss_type``,
+        ``gaussian_parametrization``, ``parametrization``, ``scheduler_type`` (enums or their string values).  The denoiser's
+        shape (input width, time-embedding width, hidden layers) is read off the weight tensors."""
+        from .model import DiffusionParameters, IsTargetConditioned, MLPDiffusion
+
+        sd = {k: (v if isinstance(v, Tensor) else torch.as_tensor(v)) for k, v in state_dict.items()}
+        proj = sd["_denoise_fn.proj.weight"]
+        dim_t, width = int(proj.shape[0]), int(proj.shape[1])
+        layers = []
+        while f"_denoise_fn.mlp.blocks.{len(layers)}.linear.weight" in sd:
+            layers.append(int(sd[f"_denoise_fn.mlp.blocks.{len(layers)}.linear.weight"].shape[0]))
+        args = dict(ctor_args)
+        args.pop("denoise_fn", None)
+        num_classes = np.asarray(args.pop("num_classes"))
+        nn_ = int(args.pop("num_numerical_features"))
+        expect = nn_ + (int(num_classes.sum()) if len(num_classes) and int(num_classes[0]) != 0 else 0)
+        if expect != width:
+            raise AssertionError(f"state dict holds a denoiser {width} wide, num_numerical_features + sum(num_classes) = {expect}")
+        coerce = {"gaussian_loss_type": GaussianLossType, "gaussian_parametrization": GaussianParametrization,
+                  "parametrization": Parametrization, "scheduler_type": SchedulerType}
+        for k, enum in coerce.items():
+            if k in args:
+                args[k] = enum(getattr(args[k], "value", args[k]))
+        net = MLPDiffusion(width, 0, IsTargetConditioned.NONE, DiffusionParameters(layers, 0.0), timestep_dimension=dim_t)
+        device = torch.device(device) if device is not None else args.pop("device", None) or _default_device()
+        args.pop("device", None)
+        model = cls(num_classes, nn_, net, device=device, **args)
+        model.load_state_dict(sd, strict=True)
+        return model.to(device)
 
     # ------------------------------------------------------------------ reverse chain
     def _reverse_chain(self, B: int, draw_outputs, model_kwargs, conditioning_function, inj: dict | None,

@@ -203,6 +203,26 @@ class Engine:
             check(_lib.lib().mtk_train_step(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), float(inv_global_batch),
                                             ptr(loss_multi), ptr(loss_gauss), seed, row0, self._stream()))
 
+    def train_forward(self, x0, t, eps, u, loss_multi=None, loss_gauss=None, seed=0, row0=0) -> int:
+        """Forward half of train_step (activations kept on the context).  Returns a token that train_backward checks."""
+        B = x0.shape[0]
+        assert x0.dtype == torch.float32 and x0.stride(1) == 1 and t.dtype == torch.int64 and t.is_contiguous()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_forward(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), ptr(loss_multi), ptr(loss_gauss),
+                                               seed, row0, self._stream()))
+        self._fwd_token = getattr(self, "_fwd_token", 0) + 1
+        return self._fwd_token
+
+    def train_backward(self, token, x0, t, eps, w_multi, w_gauss, seed=0, row0=0) -> None:
+        """Backward half: gradient image <- d(w_multi sum loss_multi + w_gauss sum loss_gauss)/d weights of the forward
+        that returned ``token`` (a later forward on this context has overwritten its activations: RuntimeError)."""
+        if token != getattr(self, "_fwd_token", None):
+            raise RuntimeError("backward through mixed_loss after another differentiable mixed_loss call on the same model: "
+                               "the context keeps the activations of one forward pass at a time")
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_backward(self._h, x0.shape[0], ptr(x0), x0.stride(0), ptr(t), ptr(eps), float(w_multi), float(w_gauss),
+                                                seed, row0, self._stream()))
+
     def train_apply(self, lr, weight_decay, step, betas=(0.9, 0.999), eps=1e-8, ema_rate=0.999) -> None:
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_train_apply(self._h, float(lr), float(weight_decay), float(betas[0]), float(betas[1]), float(eps),

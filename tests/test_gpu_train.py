@@ -271,3 +271,107 @@ def test_two_rank_training_gradient():
         assert p.exitcode == 0, p.exitcode
     res = dict(q.get() for _ in range(2))
     assert res[0] < 2e-5 and res[1] < 2e-5, res
+
+
+@pytest.mark.parametrize("tag", ["B_ragged", "A_numeric"])
+def test_reference_trainer_loop_runs_against_the_drop_in(tag):
+    """The reference's own training loop, statement for statement (TRAINER:39-51 set-up, :70-94 _train_step, :58-68 anneal,
+    :133 / :138-155 EMA), with torch.optim.AdamW and autograd: zero_grad -> mixed_loss -> (lm + lg).backward() -> step.
+    The drop-in's mixed_loss builds the graph (HIP forward + backward behind a torch.autograd.Function).  The reference's
+    draws of each iteration are injected where mixed_loss draws them; 12 iterations against tests/golden/train_*.npz with
+    the bars of test_training_run_replays_reference, and the first iteration's gradients against the oracle's autograd."""
+    from copy import deepcopy
+
+    import midst_toolkit_amd as mtk
+    from midst_toolkit_amd.trainer import update_ema
+
+    c = load_train(tag)
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    lr0, wd, steps = float(c["lr"]), float(c["wd"]), c["steps"]
+    net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(c["d_layers"]), 0.0))
+    net.load_state_dict(p0, strict=True)
+    diffusion = mtk.GaussianMultinomialDiffusion(np.asarray(c["K"]), c["Nn"], net, num_timesteps=c["T"], device=dev()).to(dev())
+    has_cat = c["K"][0] != 0
+    draws = iter(c["batches"])
+    current = {}
+
+    def fixture_draws(features):  # stands where GMD:1025-1038 draws: randint, randn_like, per-column rand_like
+        _, t, eps, u = current["batch"]
+        return t.to(dev()), eps.to(dev()), (u.to(dev()) if has_cat else None)
+
+    diffusion._draw_loss_noise = fixture_draws
+    # ---- TRAINER:39-51
+    ema_model = deepcopy(diffusion._denoise_fn)
+    for param in ema_model.parameters():
+        param.detach_()
+    optimizer = torch.optim.AdamW(diffusion.parameters(), lr=lr0, weight_decay=wd)
+    hist = []
+    for step in range(steps):
+        current["batch"] = next(draws)
+        x = current["batch"][0].to(dev())
+        target = torch.zeros(x.shape[0], dtype=torch.long, device=dev())
+        # ---- TRAINER:70-94
+        optimizer.zero_grad()
+        loss_multi, loss_gauss = diffusion.mixed_loss(x, {"y": target})
+        loss = loss_multi + loss_gauss
+        loss.backward()
+        if step == 0:
+            s = orc.make_schedule(c["T"], "cosine")
+            want, _, _ = orc.loss_and_grads(s, c["K"], c["Nn"], p0, *current["batch"])
+            got = {k: v.grad.detach().cpu() for k, v in diffusion._denoise_fn.named_parameters()}
+            assert set(got) == set(want)
+            for k in want:
+                num, den = float((got[k].double() - want[k].double()).norm()), float(want[k].double().norm())
+                assert num <= 2e-4 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+        optimizer.step()
+        # ---- TRAINER:58-68, :133
+        for group in optimizer.param_groups:
+            group["lr"] = lr0 * (1 - step / steps)
+        update_ema(ema_model.parameters(), diffusion._denoise_fn.parameters())
+        hist.append([float(loss_multi.detach()), float(loss_gauss.detach())])
+    hist, ref = np.asarray(hist), c["losses"]
+    assert np.all(np.abs(hist - ref) <= 1e-2 * np.abs(ref) + 1e-6), (hist, ref)
+    n = len(c["d_layers"])
+    final = flatten({k: v.detach().cpu() for k, v in diffusion._denoise_fn.state_dict().items()}, n).numpy()
+    ema = flatten({k: v.detach().cpu() for k, v in ema_model.state_dict().items()}, n).numpy()
+    moved = np.abs(c["final"] - flatten(p0, n).numpy())
+    err = np.abs(final - c["final"])
+    assert float(np.mean(err <= 0.05 * moved + 1e-6)) > 0.9, float(np.mean(err <= 0.05 * moved + 1e-6))
+    assert float(err.max()) <= 4 * lr0, float(err.max())
+    assert float(np.abs(ema - c["ema"]).max()) <= 4 * lr0 * 1e-3 * steps + 1e-6
+    # the trained model is usable right away on the no-grad paths (the training image is detached and the weights re-packed)
+    with torch.no_grad():
+        lm, lg = diffusion.mixed_loss(current["batch"][0].to(dev()), {"y": None})
+    assert bool(torch.isfinite(lm).all()) and bool(torch.isfinite(lg).all())
+    diffusion.precision = diffusion._denoise_fn.precision = "bf16"
+    xs, _ = diffusion.sample_all(16, 16, torch.ones(1))
+    assert xs.shape[0] == 16 and bool(torch.isfinite(xs).all())
+    # two differentiable forwards, backward through the first: refused (one set of activations per context)
+    diffusion.precision = diffusion._denoise_fn.precision = "fp32"
+    a1, b1 = diffusion.mixed_loss(x, {"y": target})
+    a2, b2 = diffusion.mixed_loss(x, {"y": target})
+    with pytest.raises(RuntimeError, match="another differentiable"):
+        (a1 + b1).backward()
+    (a2 + b2).backward()
+
+
+def test_from_reference_state_round_trip():
+    """Model ingestion from a state dict + constructor arguments: same parameters, same scores."""
+    import midst_toolkit_amd as mtk
+    from tests.helpers import case_params, load_case, tt
+
+    c = load_case("M_mixed")
+    sd = {"_denoise_fn." + k: v for k, v in case_params(c).items()}
+    ref = mtk.GaussianMultinomialDiffusion(c["K"], c["Nn"], mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(c["d_layers"]), 0.0)),
+                                           num_timesteps=c["T"], scheduler_type=mtk.SchedulerType(c["sched"]), device=torch.device("cpu"))
+    sd.update({k: v for k, v in ref.state_dict().items() if not k.startswith("_denoise_fn.")})
+    d = mtk.GaussianMultinomialDiffusion.from_reference_state(sd, {"num_classes": c["K"], "num_numerical_features": c["Nn"], "num_timesteps": c["T"],
+                                                                   "scheduler_type": c["sched"]}, device=dev())
+    assert [int(b.linear.out_features) for b in d._denoise_fn.mlp.blocks] == list(c["d_layers"])
+    x, t = tt(c["ml_model_in"]).to(dev()), tt(c["ml_t"]).to(dev())
+    with torch.no_grad():
+        out = d._denoise_fn(x, t)
+    want = tt(c["ml_model_out"])
+    assert float((out.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    with pytest.raises(AssertionError):
+        mtk.GaussianMultinomialDiffusion.from_reference_state(sd, {"num_classes": c["K"], "num_numerical_features": c["Nn"] + 1}, device=dev())
