@@ -98,6 +98,16 @@ void mtk_ctx_destroy(mtk_ctx* ctx);
 /* No reference counterpart: selects enum mtk_math for this context's diffusion kernels. */
 int mtk_ctx_set_math(mtk_ctx* ctx, int mode);
 
+/* No reference counterpart (capture-ready contract): sizes every workspace of the context for calls of up to
+ * max_rows rows through the denoiser (B for mtk_mlp_forward and the training entry points, B * P for mtk_tf_score).  Afterwards
+ * those entry points neither allocate nor synchronise for such calls, so they can be captured into a HIP graph.  The call
+ * itself may synchronise `stream` and allocate; the reservation only grows and survives mtk_mlp_set_weights. */
+int mtk_ctx_reserve(mtk_ctx* ctx, int64_t max_rows, mtk_stream stream);
+/* No reference counterpart: the reverse-chain kernels (mtk_sample_init, mtk_p_sample_step[_guided], mtk_ddim_step) take their
+ * Philox seed and first global row from the device pair {seed, row0} at seed_row0_dev instead of from their arguments (NULL:
+ * back to the arguments) - a captured chain is replayed with new noise by rewriting 16 bytes. */
+int mtk_ctx_set_seed_source(mtk_ctx* ctx, const uint64_t* seed_row0_dev);
+
 /* Replaces MLPDiffusion's parameter storage (MODEL:548-594).  W[i] / b[i] are device pointers to
  * fp32 PyTorch-layout weights [out_i][in_i] / [out_i], in this order:
  *   0 proj, 1 timestep_embedding.0, 2 timestep_embedding.2, 3.. mlp.blocks.*.linear, last mlp.head

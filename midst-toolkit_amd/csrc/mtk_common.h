@@ -82,6 +82,8 @@ struct mtk_ctx {
     int32_t* d_off = nullptr;
     float* d_logK = nullptr;
     double* d_kl = nullptr;  // [T][4]: posterior_mean_coef1/2, posterior_log_variance_clipped, model log-variance (KL Gaussian loss; built on first use)
+    const uint64_t* seed_src = nullptr;  // device {seed, row0} read by the reverse-chain kernels instead of their arguments (graph replay)
+    int64_t reserved_rows = 0;           // mtk_ctx_reserve: workspaces stay sized for calls of up to this many rows
     bool fast_math = false;  // MTK_MATH_FAST: diffusion kernels on hardware transcendentals, exact block LSE
     // denoiser
     bool have_weights = false;

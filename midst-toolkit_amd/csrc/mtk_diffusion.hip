@@ -287,17 +287,20 @@ struct StepArgs {
     const float* u;
     float* x_in; int64_t xi_rs, xi_cs;
     uint64_t seed, row0;
+    const uint64_t* seed_src;  // optional device {seed, row0} overriding the two above (graph replay)
 };
 
 __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
     const Staged s = stage_tables<false>(a.d);
+    // seed / first global row: kernel arguments, or - for launches replayed from a HIP graph - a device pair (mtk_ctx_set_seed_source)
+    const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S, t = a.t;
     const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)t, stream_u = stream_n + 1u;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const float* mo = a.mo + row * a.mo_rs;
         float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
-        PhiloxN pn(a.seed, a.row0 + row, stream_n);
-        PhiloxU pu(a.seed, a.row0 + row, stream_u);
+        PhiloxN pn(seed_, row0_ + row, stream_n);
+        PhiloxU pu(seed_, row0_ + row, stream_u);
         for (int j = 0; j < Nn; ++j) {
             const float eh = mo[j * a.mo_cs];
             double* zp = a.z + (int64_t)j * a.B + row;
@@ -382,16 +385,19 @@ struct DdimArgs {
     const float* u;
     float* x_in; int64_t xi_rs, xi_cs;
     uint64_t seed, row0;
+    const uint64_t* seed_src;
 };
 
 __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
     const Staged s = stage_tables<false>(a.d);
+    // seed / first global row: kernel arguments, or - for launches replayed from a HIP graph - a device pair (mtk_ctx_set_seed_source)
+    const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     const uint32_t stream_u = MTK_STREAM_STEP + 2u * (uint32_t)a.t + 1u;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const float* mo = a.mo + row * a.mo_rs;
         float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
-        PhiloxU pu(a.seed, a.row0 + row, stream_u);
+        PhiloxU pu(seed_, row0_ + row, stream_u);
         for (int j = 0; j < Nn; ++j) {
             double* zp = a.z + (int64_t)j * a.B + row;
             const float zf = (float)*zp, eh = mo[j * a.mo_cs];
@@ -437,15 +443,18 @@ struct InitArgs {
     int32_t* z_idx;
     float* x_in; int64_t xi_rs, xi_cs;
     uint64_t seed, row0;
+    const uint64_t* seed_src;
 };
 
 __global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
     const Staged s = stage_tables<false>(a.d);
+    // seed / first global row: kernel arguments, or - for launches replayed from a HIP graph - a device pair (mtk_ctx_set_seed_source)
+    const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         float* xo = a.x_in + row * a.xi_rs;
-        PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_Z0);
-        PhiloxU pu(a.seed, a.row0 + row, MTK_STREAM_U0);
+        PhiloxN pn(seed_, row0_ + row, MTK_STREAM_Z0);
+        PhiloxU pu(seed_, row0_ + row, MTK_STREAM_U0);
         for (int j = 0; j < Nn; ++j) {
             const float v = a.z0 ? a.z0[row * Nn + j] : pn.normal(j);
             a.z[(int64_t)j * a.B + row] = (double)v;
@@ -883,14 +892,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 template <int KC>
 __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
     const Staged s = stage_tables<false>(a.d);
+    // seed / first global row: kernel arguments, or - for launches replayed from a HIP graph - a device pair (mtk_ctx_set_seed_source)
+    const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S, t = a.t;
     const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)t, stream_u = stream_n + 1u;
     constexpr int G = 4;  // numeric columns per load group (fp64 state: 2 registers each)
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const float* mo = a.mo + row * a.mo_rs;
         float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
-        PhiloxNF pn(a.seed, a.row0 + row, stream_n);
-        PhiloxW pu(a.seed, a.row0 + row, stream_u);
+        PhiloxNF pn(seed_, row0_ + row, stream_n);
+        PhiloxW pu(seed_, row0_ + row, stream_u);
         // the first categorical block's inputs go out before the numeric part is consumed
         BlockRaw<KC> raw;
         int cz = 0;
@@ -1353,7 +1364,7 @@ extern "C" int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int firs
     a.grad = grad;
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
     a.z = z; a.z_idx = z_idx; a.noise = noise; a.noise_f64 = noise_is_f64; a.u = u;
-    a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
+    a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0; a.seed_src = ctx->seed_src;
     auto kstep = !ctx->fast_math ? k_p_sample_step : (max_levels(ctx) <= kKCacheSmall ? k_p_sample_step_fast<kKCacheSmall> : k_p_sample_step_fast<kKCache>);
     hipLaunchKernelGGL(kstep, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false),
                        (hipStream_t)stream, a);
@@ -1390,7 +1401,7 @@ extern "C" int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_
     a.log_c3 = coef3 > 0.0f ? logf(coef3) : -INFINITY;
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
     a.z = z; a.z_idx = z_idx; a.u = u;
-    a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0;
+    a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0; a.seed_src = ctx->seed_src;
     hipLaunchKernelGGL(k_ddim_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -1402,7 +1413,7 @@ extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const f
     if (B < 0 || !x_in || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null pointer or negative B");
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
-    InitArgs a{ctx->dev(), B, z0, u0, z, z_idx, x_in, xi_rs, xi_cs, seed, row0};
+    InitArgs a{ctx->dev(), B, z0, u0, z, z_idx, x_in, xi_rs, xi_cs, seed, row0, ctx->seed_src};
     hipLaunchKernelGGL(k_sample_init, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -1443,6 +1454,12 @@ extern "C" int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const
     hipLaunchKernelGGL(k_sample_decode, dim3(grid_for(B * (ctx->Nn + ctx->C))), dim3(kBlock), 0, (hipStream_t)stream, B,
                        ctx->Nn, ctx->C, z, z_idx, sample);
     MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_ctx_set_seed_source(mtk_ctx* ctx, const uint64_t* seed_row0_dev) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_set_seed_source: null context");
+    ctx->seed_src = seed_row0_dev;
     return MTK_OK;
 }
 

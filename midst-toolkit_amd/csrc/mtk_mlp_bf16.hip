@@ -739,6 +739,20 @@ int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64
     return rc ? rc : mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
 }
 
+// compact [records][round_up(Nn, 4)] copy of the records (used when the caller's rows are not 16-byte aligned / compact)
+int mtk_reserve_fused_tf(mtk_ctx* c, int64_t records, hipStream_t s) {
+    if (!c->fused_ok) return MTK_OK;
+    const size_t need = (size_t)records * ((c->D + 3) & ~3);
+    if (need <= c->tf_pack_elems) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    if (c->tf_pack) (void)hipFree(c->tf_pack);
+    c->tf_pack = nullptr;
+    c->tf_pack_elems = 0;
+    MTK_HIP(hipMalloc(&c->tf_pack, sizeof(float) * need));
+    c->tf_pack_elems = need;
+    return MTK_OK;
+}
+
 // Returns MTK_ERR_UNSUPPORTED (without setting up anything) when the staged-record layout cannot hold this shape:
 // the caller then runs noising / denoiser / MSE as three kernels.
 int mtk_fused_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_t x_ld, const float* noise, int n_t,
@@ -758,15 +772,8 @@ int mtk_fused_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_t x_l
     const float* xs = x;
     int64_t xs_ld = x_ld;
     if (x_ld != ld || (reinterpret_cast<uintptr_t>(x) & 15)) {
-        const size_t need = (size_t)B * ld;
-        if (need > c->tf_pack_elems) {
-            MTK_HIP(hipStreamSynchronize(s));
-            if (c->tf_pack) (void)hipFree(c->tf_pack);
-            c->tf_pack = nullptr;
-            c->tf_pack_elems = 0;
-            MTK_HIP(hipMalloc(&c->tf_pack, sizeof(float) * need));
-            c->tf_pack_elems = need;
-        }
+        const int rcp = mtk_reserve_fused_tf(c, B, s);
+        if (rcp) return rcp;
         hipLaunchKernelGGL(k_compact_rows, dim3(1024), dim3(256), 0, s, c->tf_pack, ld, x, x_ld, B, c->D);
         MTK_HIP(hipGetLastError());
         xs = c->tf_pack;

@@ -586,6 +586,23 @@ int64_t chunk_rows(int maxld, bool split) {
     return chunk;
 }
 
+// bf16 activation ping-pong for calls of up to B rows (grown on demand, or ahead of time by mtk_ctx_reserve)
+int ensure_ws16(mtk_ctx* c, int64_t B, bool split, hipStream_t s) {
+    const int maxld = max_ld_layered(c);
+    const int64_t chunk = chunk_rows(maxld, split);
+    const int64_t need_rows = (B < chunk ? (B + kRowPad - 1) / kRowPad * kRowPad : chunk);
+    const size_t need = (size_t)need_rows * maxld * (split ? 2 : 1);
+    if (need <= c->ws16_elems) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 2; ++i) {
+        if (c->ws16[i]) (void)hipFree(c->ws16[i]);
+        c->ws16[i] = nullptr;
+        MTK_HIP(hipMalloc(&c->ws16[i], sizeof(uint16_t) * need));
+    }
+    c->ws16_elems = need;
+    return MTK_OK;
+}
+
 template <bool SPLIT>
 int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar, float* out,
                     int64_t o_rs, int64_t o_cs, hipStream_t s) {
@@ -594,17 +611,8 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
     constexpr int F = SPLIT ? 2 : 1;  // bf16 numbers per activation / weight
     const int maxld = max_ld_layered(c);
     const int64_t chunk = chunk_rows(maxld, SPLIT);
-    const int64_t need_rows = (B < chunk ? (B + kRowPad - 1) / kRowPad * kRowPad : chunk);
-    const size_t need = (size_t)need_rows * maxld * F;
-    if (need > c->ws16_elems) {
-        MTK_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < 2; ++i) {
-            if (c->ws16[i]) (void)hipFree(c->ws16[i]);
-            c->ws16[i] = nullptr;
-            MTK_HIP(hipMalloc(&c->ws16[i], sizeof(uint16_t) * need));
-        }
-        c->ws16_elems = need;
-    }
+    int rc0;
+    if ((rc0 = ensure_ws16(c, B, SPLIT, s))) return rc0;
     uint16_t* ws[2] = {reinterpret_cast<uint16_t*>(c->ws16[0]), reinterpret_cast<uint16_t*>(c->ws16[1])};
     for (int64_t r0 = 0; r0 < B; r0 += chunk) {
         const int64_t M = (B - r0 < chunk) ? B - r0 : chunk;
@@ -648,6 +656,11 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
 }
 
 }  // namespace
+
+int mtk_reserve_layered(mtk_ctx* c, int64_t rows, hipStream_t s) {  // mtk_ctx_reserve: the split image is the larger one
+    if (c->wb16x.empty() && c->wb16.empty()) return MTK_OK;
+    return ensure_ws16(c, rows, !c->wb16x.empty(), s);
+}
 
 int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                              float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {

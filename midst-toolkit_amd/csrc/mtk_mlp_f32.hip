@@ -227,6 +227,8 @@ void mtk_free_mlp(mtk_ctx* c) {
     c->have_weights = false;
 }
 
+static int reserve_all(mtk_ctx* c, int64_t rows, hipStream_t s);  // below: re-applies an mtk_ctx_reserve reservation
+
 extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims_host, const float* const* W,
                                    const float* const* b, const float* freqs_host, mtk_stream stream) {
     if (!c || !dims_host || !W || !b || !freqs_host) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: null argument");
@@ -285,7 +287,8 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
     if ((rc = mtk_pack_fused(c, s))) return rc;
     // split-bf16 weight images for MTK_PREC_BF16X3 (every shape); shapes the fused kernel does not cover also get plain bf16
     // images for the layer-by-layer bf16 MFMA path
-    return mtk_pack_layered(c, s, !c->fused_ok);
+    if ((rc = mtk_pack_layered(c, s, !c->fused_ok))) return rc;
+    return c->reserved_rows > 0 ? reserve_all(c, c->reserved_rows, s) : MTK_OK;
 }
 
 // Exact-fp32 forward for `B` rows (at most `chunk` at a pass) through the activation ping-pong buffers ws0 / ws1
@@ -329,22 +332,56 @@ static int max_pad_of(const mtk_ctx* c) {
     return maxpad;
 }
 
+constexpr int64_t kChunkF32 = 65536;  // rows per pass of the fp32 layer chain
+
+// Sizes the fp32 activation ping-pong for calls of up to B rows (the only place the fp32 path allocates: it synchronises
+// the stream and reallocates when a larger B arrives - ahead of time through mtk_ctx_reserve, or on demand).
+static int ensure_ws_f32(mtk_ctx* c, int64_t B, hipStream_t s) {
+    const int64_t need_rows = (B < kChunkF32 ? (B + BM - 1) / BM * BM : kChunkF32);
+    const size_t need = (size_t)need_rows * max_pad_of(c);
+    if (need <= c->ws_elems) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 2; ++i) {
+        if (c->ws[i]) (void)hipFree(c->ws[i]);
+        c->ws[i] = nullptr;
+        MTK_HIP(hipMalloc(&c->ws[i], sizeof(float) * need));
+    }
+    c->ws_elems = need;
+    return MTK_OK;
+}
+
 // Exact-fp32 forward through the context-owned workspace (grown on demand, or ahead of time by mtk_ctx_reserve).
 static int forward_f32(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                        float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
-    const int64_t chunk = 65536;
-    const int64_t need_rows = (B < chunk ? (B + BM - 1) / BM * BM : chunk);
-    const size_t need = (size_t)need_rows * max_pad_of(c);
-    if (need > c->ws_elems) {
-        MTK_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < 2; ++i) {
-            if (c->ws[i]) (void)hipFree(c->ws[i]);
-            c->ws[i] = nullptr;
-            MTK_HIP(hipMalloc(&c->ws[i], sizeof(float) * need));
-        }
-        c->ws_elems = need;
-    }
-    return forward_f32_ws(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, c->ws[0], c->ws[1], chunk, s);
+    const int rc = ensure_ws_f32(c, B, s);
+    if (rc) return rc;
+    return forward_f32_ws(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, c->ws[0], c->ws[1], kChunkF32, s);
+}
+
+int mtk_reserve_layered(mtk_ctx* c, int64_t rows, hipStream_t s);  // mtk_mlp_bf16_layered.hip
+int mtk_reserve_tf(mtk_ctx* c, int64_t rows, hipStream_t s);       // mtk_tf.hip
+int mtk_reserve_train(mtk_ctx* c, int64_t rows, hipStream_t s);    // mtk_train.hip
+
+static int reserve_all(mtk_ctx* c, int64_t rows, hipStream_t s) {
+    int rc;
+    if ((rc = ensure_ws_f32(c, rows, s))) return rc;
+    if ((rc = mtk_reserve_layered(c, rows, s))) return rc;
+    if ((rc = mtk_reserve_tf(c, rows, s))) return rc;
+    return mtk_reserve_train(c, rows, s);
+}
+
+// No reference counterpart ("scratch sized at create/first use ... never synchronises"): sizes every workspace
+// of the context for calls of up to max_rows rows through the denoiser (B for mtk_mlp_forward / mtk_train_step, B * P for
+// mtk_tf_score), so that none of those entry points allocates or synchronises afterwards - what a caller needs before
+// capturing them into a HIP graph.  This call itself may synchronise the stream and allocate.  The reservation survives
+// mtk_mlp_set_weights (re-applied there) and only ever grows.
+extern "C" int mtk_ctx_reserve(mtk_ctx* c, int64_t max_rows, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_reserve: null context");
+    if (max_rows < 0) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_reserve: negative row count");
+    if (max_rows > c->reserved_rows) c->reserved_rows = max_rows;
+    if (!c->have_weights || c->reserved_rows == 0) return MTK_OK;  // applied when the weights are set
+    MTK_HIP(hipSetDevice(c->device));
+    return reserve_all(c, c->reserved_rows, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

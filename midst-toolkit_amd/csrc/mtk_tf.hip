@@ -41,7 +41,31 @@ int grid_for(int64_t n) {
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 
+// x_t / eps_hat buffers of the unfused path for `rows` rows (records x noise draws) through the denoiser
+int ensure_tf_ws(mtk_ctx* c, int64_t rows, hipStream_t s) {
+    const size_t need = (size_t)rows * c->Nn;
+    if (need <= c->tf_ws_elems) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 2; ++i) {
+        if (c->tf_ws[i]) (void)hipFree(c->tf_ws[i]);
+        c->tf_ws[i] = nullptr;
+        MTK_HIP(hipMalloc(&c->tf_ws[i], sizeof(float) * need));
+    }
+    c->tf_ws_elems = need;
+    return MTK_OK;
+}
+
 }  // namespace
+
+int mtk_reserve_fused_tf(mtk_ctx* c, int64_t records, hipStream_t s);  // mtk_mlp_bf16.hip
+
+// mtk_ctx_reserve: rows = records x noise draws; the compact record copy of the fused kernel is sized for `rows` records
+int mtk_reserve_tf(mtk_ctx* c, int64_t rows, hipStream_t s) {
+    if (c->S != 0 || c->Nn == 0) return MTK_OK;  // Tartan-Federer scoring is defined for numeric-only contexts
+    int rc = ensure_tf_ws(c, rows < (1 << 20) ? rows : (1 << 20), s);
+    if (rc) return rc;
+    return mtk_reserve_fused_tf(c, rows, s);
+}
 
 extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_t x_ld, const float* noise, int n_t,
                             const int32_t* t_list_host, int add_t, float* score, int precision, mtk_stream stream) {
@@ -71,15 +95,9 @@ extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_
 
     const int Nn = c->Nn;
     const int64_t rec_chunk = (1 << 20) / P > 0 ? (1 << 20) / P : 1;  // <= 1M rows per pass
-    const size_t need = (size_t)((B < rec_chunk ? B : rec_chunk) * P) * Nn;
-    if (need > c->tf_ws_elems) {
-        MTK_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < 2; ++i) {
-            if (c->tf_ws[i]) (void)hipFree(c->tf_ws[i]);
-            c->tf_ws[i] = nullptr;
-            MTK_HIP(hipMalloc(&c->tf_ws[i], sizeof(float) * need));
-        }
-        c->tf_ws_elems = need;
+    {
+        const int rc = ensure_tf_ws(c, (B < rec_chunk ? B : rec_chunk) * P, s);
+        if (rc) return rc;
     }
     for (int k = 0; k < n_t; ++k) {
         const int t = t_list_host[k];

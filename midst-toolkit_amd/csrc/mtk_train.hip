@@ -397,6 +397,12 @@ int kchunk_for(int64_t K, int tiles) {
 
 }  // namespace
 
+int mtk_reserve_train(mtk_ctx* c, int64_t rows, hipStream_t s) {  // mtk_ctx_reserve: activations of a training iteration
+    if (!c->train.attached || rows <= 0) return MTK_OK;
+    if (rows > (1 << 22)) rows = 1 << 22;
+    return ensure_acts(c, (rows + TM - 1) / TM * TM, s);
+}
+
 void mtk_free_train(mtk_ctx* c) {
     TrainState& tr = c->train;
     auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };

@@ -139,6 +139,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         self.results_on_device = False  # True: sample / sample_all return device tensors (the reference moves them to the CPU, GMD:1423),
         #                                 so that e.g. transforms.QuantileInverse runs on them without a host round trip
         self.rng = "torch"  # "torch": draw like the reference does; "philox": draw inside the kernels
+        self.use_graph = False  # rng="philox" only: run the reverse chain of sample() as one captured HIP graph (_replay_chain_graph)
         self.math = None    # None: "fast" with rng="philox", "reference" otherwise; or force "reference"/"fast"
         self.precision = getattr(denoise_fn, "precision", "fp32")
         self._engine: Engine | None = None
@@ -149,6 +150,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         state = dict(self.__dict__)
         state["_engine"] = None
         state.pop("_aux", None)
+        state.pop("_graphs", None)
         return state
 
     @property
@@ -399,17 +401,15 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             z0 = torch.randn((B, Nn), device=dev)
             u0 = draw_u() if C else None
         outputs = draw_outputs()
+        if philox and not ddim and conditioning_function is None and getattr(self, "use_graph", False):
+            sample = self._replay_chain_graph(eng, B, seed, row0)
+            return (sample if getattr(self, "results_on_device", False) else sample.cpu()), outputs
         z = torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev)
         z_idx = torch.empty((max(C, 1), B), dtype=torch.int32, device=dev)
         x_in = torch.empty((D, B), dtype=torch.float32, device=dev)
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
         eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed, row0)
-        graph = self._chain_graph(eng, B, x_in, out, z, z_idx, seed, row0) if (philox and not ddim and conditioning_function is None) else None
-        if graph is not None:
-            graph.replay()
         for i, t in enumerate(reversed(range(T))):
-            if graph is not None:
-                break
             self._denoise_cm(eng, x_in, t, B, out)
             n = u = grad = None
             if inj is not None:
@@ -434,10 +434,52 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         sample = sample.float() if ddim else sample  # the reference's DDIM chain is fp32 end to end
         return (sample if getattr(self, "results_on_device", False) else sample.cpu()), outputs
 
-    def _chain_graph(self, eng: Engine, B, x_in, out, z, z_idx, seed, row0):
-        """HIP-graph capture of the T-loop (``use_graph``; in-kernel noise only: no host draws inside the loop).  Off by
-        default; see ``capture_chain``."""
-        return None
+    def _replay_chain_graph(self, eng: Engine, B: int, seed: int, row0: int) -> Tensor:
+        """The whole reverse chain of ``B`` rows - mtk_sample_init, T x (denoiser, mtk_p_sample_step), mtk_sample_decode: 2 T + 2
+        launches - as ONE HIP graph (GMD:1403-1417 is a Python loop of T iterations in the reference).  In-kernel Philox noise
+        only: no host draw happens inside the loop, and the kernels read {seed, row0} from a 16-byte device buffer
+        (mtk_ctx_set_seed_source), so one captured graph serves every later call with the same batch size and weights.
+        Captured once per (batch size, packed weights, precision, math) after mtk_ctx_reserve has sized the workspaces;
+        replays allocate nothing and make one launch call.  Same kernels and arguments as the eager loop: same samples."""
+        dev = eng.device
+        Nn, C, D, T = eng.Nn, eng.C, eng.D, self.num_timesteps
+        key = (B, str(dev), self.precision, self.math, getattr(self._denoise_fn, "_synced_key", None), id(eng))
+        cache = self.__dict__.setdefault("_graphs", {})
+        ent = cache.get(key)
+        if ent is None:
+            while len(cache) >= 4:  # static buffers per entry: keep a few batch sizes
+                cache.pop(next(iter(cache)))
+            ent = {"seed": torch.zeros(2, dtype=torch.int64, device=dev),
+                   "z": torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev),
+                   "z_idx": torch.empty((max(C, 1), B), dtype=torch.int32, device=dev),
+                   "x_in": torch.empty((D, B), dtype=torch.float32, device=dev),
+                   "out": torch.empty((D, B), dtype=torch.float32, device=dev),
+                   "sample": torch.empty((B, Nn + C), dtype=torch.float64, device=dev)}
+            eng.reserve(B)
+
+            def chain(steps):
+                eng.sample_init(B, None, None, ent["z"], ent["z_idx"], ent["x_in"], (1, B), 0, 0)
+                for i, t in enumerate(reversed(range(T))):
+                    if i >= steps:
+                        break
+                    self._denoise_cm(eng, ent["x_in"], t, B, ent["out"])
+                    eng.p_sample_step(B, t, i == 0, ent["out"], (1, B), ent["z"], ent["z_idx"], None, None, ent["x_in"], (1, B), 0, 0)
+                eng.sample_decode(B, ent["z"], ent["z_idx"], ent["sample"])
+
+            eng.set_seed_source(ent["seed"])
+            try:
+                chain(2)  # eager warm-up: one-time function attributes and device queries happen outside the capture
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    chain(T)
+            finally:
+                eng.set_seed_source(None)
+            ent["graph"] = graph
+            cache[key] = ent
+        ent["seed"].copy_(torch.tensor([seed, row0], dtype=torch.int64))
+        ent["graph"].replay()
+        return ent["sample"].clone()
 
     def _target_fn(self, batch_size: int, target_dist: Tensor, inj: dict | None):
         def draw():

@@ -69,6 +69,19 @@ class Engine:
         """"reference" (parity, default) or "fast" (hardware transcendentals, exact block log-sum-exp)."""
         check(_lib.lib().mtk_ctx_set_math(self._h, {"reference": 0, "fast": 1}[mode]))
 
+    def reserve(self, max_rows: int) -> None:
+        """Size every workspace for calls of up to ``max_rows`` rows: afterwards no entry point allocates or synchronises
+        (needed before capturing calls into a HIP graph)."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_ctx_reserve(self._h, int(max_rows), self._stream()))
+
+    def set_seed_source(self, seed_row0: torch.Tensor | None) -> None:
+        """``seed_row0``: int64 [2] device tensor {seed, row0} the reverse-chain kernels read instead of their arguments."""
+        if seed_row0 is not None:
+            assert seed_row0.is_cuda and seed_row0.dtype == torch.int64 and seed_row0.numel() == 2 and seed_row0.is_contiguous()
+        self._seed_src = seed_row0  # keeps it alive
+        check(_lib.lib().mtk_ctx_set_seed_source(self._h, ptr(seed_row0)))
+
     def _stream(self):
         return _lib.stream_handle(self.device)
 

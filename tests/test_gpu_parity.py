@@ -976,3 +976,32 @@ def test_philox_categorical_distributions():
     eng.sample_init(B, None, None, z, zid, x_in, (1, B), seed=9)
     check(zid, torch.ones(int(np.sum(K))), "sample_init")
     assert abs(float(z[:Nn].mean())) < 6 / (B * Nn) ** 0.5 and abs(float(z[:Nn].std()) - 1) < 0.01
+
+
+@pytest.mark.parametrize("tag,precision", [("M_mixed", "bf16"), ("B_ragged", "fp32"), ("A_numeric", "bf16x3")])
+def test_graph_replayed_chain_equals_eager_chain(tag, precision):
+    """sample() with use_graph: the T-loop (GMD:1403-1417) replayed as one captured HIP graph gives bit-for-bit the rows of
+    the eager loop (same kernels, same arguments; seed and first row come from the 16-byte device pair), a captured graph
+    is reused across seeds and row offsets, and mtk_ctx_reserve made the entry points capture-safe."""
+    c = load_case(tag)
+    d = build(c, precision=precision, T=60)
+    d.rng = "philox"
+    B = 300
+    eager1, _ = d.sample(B, torch.ones(1), seed=11, row0=0)
+    eager2, _ = d.sample(B, torch.ones(1), seed=12, row0=1000)
+    d.use_graph = True
+    graph1, _ = d.sample(B, torch.ones(1), seed=11, row0=0)
+    assert len(d._graphs) == 1
+    graph2, _ = d.sample(B, torch.ones(1), seed=12, row0=1000)   # same graph, new 16 bytes
+    assert len(d._graphs) == 1
+    assert torch.equal(graph1, eager1) and torch.equal(graph2, eager2)
+    assert not torch.equal(graph1, graph2)
+    # rows are a function of (seed, global row): a shifted window of the same stream
+    shifted, _ = d.sample(B, torch.ones(1), seed=11, row0=100)
+    assert torch.equal(shifted[: B - 100], graph1[100:])
+    # sample_all drives it batch after batch, continuing the row range
+    x, y = d.sample_all(2 * B, B, torch.ones(1), seed=11)
+    assert torch.equal(x[:B], graph1) and x.shape[0] == 2 * B
+    d.use_graph = False
+    x2, _ = d.sample_all(2 * B, B, torch.ones(1), seed=11)
+    assert torch.equal(x2, x)
