@@ -281,6 +281,29 @@ int mtk_train_apply(mtk_ctx* ctx, double lr, double weight_decay, double beta1, 
 int mtk_train_export(mtk_ctx* ctx, int image, float* const* W, float* const* b, mtk_stream stream);
 int mtk_train_import(mtk_ctx* ctx, int image, const float* const* W, const float* const* b, mtk_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Classifier guidance.  Replaces the eval-mode forward of `Classifier`
+ * (models/clavaddpm/model.py:45-120) and the input gradient its conditioning function takes through autograd
+ * (models/clavaddpm/synthesizer.py:429-451): grad = scale * d log_softmax(classifier(x, t))[y] / d x, what
+ * condition_mean (GMD:585-615) adds to the posterior mean through mtk_p_sample_step_guided.
+ *
+ * Network handed over: h0 = proj(x) + emb[t]; then n_lin Linear layers, layer i < n_lin - 1 followed by ReLU
+ * (slopes_host[i] == 0) or LeakyReLU (its negative slope).  widths_host[n_lin] = output widths of those layers (the last
+ * is the number of classes).  W / b (device, fp32, PyTorch layout [out][in] / [out]) in the order proj,
+ * timestep_embedding.0, timestep_embedding.2, then the n_lin layers - with each eval-mode BatchNorm1d (an affine map
+ * per feature) folded into the Linear that FOLLOWS it by the caller; Dropout is the identity in eval mode; the
+ * nn.Transformer the reference constructs (MODEL:73) is never called by its forward.  freqs_host as in
+ * mtk_mlp_set_weights.  The [T, dim_t] time-embedding table is built by the call.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mtk_clf mtk_clf;
+int mtk_clf_create(int device, int T, int D_in, int dim_t, int n_lin, const int32_t* widths_host, const float* slopes_host,
+                   const float* const* W, const float* const* b, const float* freqs_host, mtk_stream stream, mtk_clf** out);
+void mtk_clf_destroy(mtk_clf* clf);
+/* x: [B, x_ld] row-major fp32 (x_ld >= D_in); t: [B] int64; y: [B] int64 class indices (needed for grad).  logits: [B, n_out]
+ * row-major or NULL; grad: [B, D_in] row-major or NULL.  Rows whose timestep lies outside [0, T) come back NaN. */
+int mtk_clf_guidance(mtk_clf* clf, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,
+                     float* logits, float* grad, mtk_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+"""Drop-in for the reference's guidance classifier (models/clavaddpm/model.py:45-120) and its conditioning function
+(models/clavaddpm/synthesizer.py:429-451) on MI355X.
+
+``Classifier`` has the reference's constructor, parameter names and ``forward(input_tensor, timesteps)``; a state dict of
+the reference's trained classifier loads into it (its ``transformer_layer.*`` entries - an ``nn.Transformer`` the
+reference constructs at MODEL:73 and never calls - are accepted and dropped).  In eval mode, which is how the synthesizer
+uses it (TRAIN:447), the forward pass and the input gradient of ``log_softmax(logits)[y]`` run in libmtk_hip.so
+(``mtk_clf_guidance``: fp32 MFMA GEMMs forward, a hand-written backward; no autograd).  Training the classifier
+(BatchNorm batch statistics, Dropout) is not on this path: train it with the reference's module and load the result.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from ._lib import check, ptr
+from .model import timestep_frequencies
+
+
+class Classifier(nn.Module):
+    def __init__(self, input_dimension: int, output_dimension: int, timestep_dimension: int, hidden_sizes: list[int],
+                 dropout_prob: float = 0.5, num_heads: int = 2, num_layers: int = 1, num_timesteps: int = 1000):
+        """MODEL:46-101.  ``num_timesteps`` (not in the reference): size of the time-embedding table."""
+        super().__init__()
+        self.timestep_dimension = timestep_dimension
+        self.input_dimension, self.output_dimension = input_dimension, output_dimension
+        self.num_timesteps = num_timesteps
+        self.proj = nn.Linear(input_dimension, timestep_dimension)
+        self.timestep_embedding = nn.Sequential(nn.Linear(timestep_dimension, timestep_dimension), nn.SiLU(),
+                                                nn.Linear(timestep_dimension, timestep_dimension))
+        layers: list[nn.Module] = [nn.Linear(timestep_dimension, hidden_sizes[0]), nn.ReLU(), nn.BatchNorm1d(hidden_sizes[0]), nn.Dropout(p=dropout_prob)]
+        for i in range(len(hidden_sizes) - 1):
+            layers += [nn.Linear(hidden_sizes[i], hidden_sizes[i + 1]), nn.LeakyReLU(), nn.BatchNorm1d(hidden_sizes[i + 1]), nn.Dropout(p=dropout_prob)]
+        layers.append(nn.Linear(hidden_sizes[-1], output_dimension))
+        self.model = nn.Sequential(*layers)
+        self._handle = None
+        self._handle_key = None
+
+    # ------------------------------------------------------------------ state
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Accepts the reference classifier's state dict: the never-called nn.Transformer's entries are dropped."""
+        kept = {k: v for k, v in state_dict.items() if not k.startswith("transformer_layer.")}
+        return super().load_state_dict(kept, strict=strict, assign=assign)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_handle"], state["_handle_key"] = None, None
+        return state
+
+    def __del__(self):
+        try:
+            h = self.__dict__.get("_handle")
+            self.__dict__["_handle"] = None
+            if h:
+                _lib.lib().mtk_clf_destroy(h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ the network as the library takes it
+    def _folded_layers(self):
+        """[(W, b)] for proj, timestep_embedding.0, timestep_embedding.2 and the Linear layers of ``model`` with every
+        eval-mode BatchNorm1d (y * s + o per feature, s = gamma / sqrt(var + eps), o = beta - mean * s) folded into the
+        Linear that follows it: W' = W diag(s), b' = b + W o.  Plus the activation slope after each hidden Linear."""
+        out = [(self.proj.weight, self.proj.bias), (self.timestep_embedding[0].weight, self.timestep_embedding[0].bias),
+               (self.timestep_embedding[2].weight, self.timestep_embedding[2].bias)]
+        slopes, widths = [], []
+        scale = offset = None
+        for m in self.model:
+            if isinstance(m, nn.Linear):
+                W, b = m.weight.detach().double(), m.bias.detach().double()
+                if scale is not None:
+                    b = b + W @ offset
+                    W = W * scale[None, :]
+                    scale = offset = None
+                out.append((W.float().contiguous(), b.float().contiguous()))
+                widths.append(int(m.out_features))
+            elif isinstance(m, nn.ReLU):
+                slopes.append(0.0)
+            elif isinstance(m, nn.LeakyReLU):
+                slopes.append(float(m.negative_slope))
+            elif isinstance(m, nn.BatchNorm1d):
+                s = m.weight.detach().double() / torch.sqrt(m.running_var.detach().double() + m.eps)
+                scale, offset = s, m.bias.detach().double() - m.running_mean.detach().double() * s
+        return out, slopes, widths
+
+    def _engine(self, device: torch.device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        if self._handle is not None:
+            _lib.lib().mtk_clf_destroy(self._handle)
+            self._handle = None
+        layers, slopes, widths = self._folded_layers()
+        keep = [(W.detach().float().contiguous().to(device), b.detach().float().contiguous().to(device)) for W, b in layers]
+        Wp = (C.c_void_p * len(keep))(*[W.data_ptr() for W, _ in keep])
+        bp = (C.c_void_p * len(keep))(*[b.data_ptr() for _, b in keep])
+        w32 = np.ascontiguousarray(np.asarray(widths, dtype=np.int32))
+        sl = np.ascontiguousarray(np.asarray(slopes + [0.0], dtype=np.float32))
+        fr = np.ascontiguousarray(timestep_frequencies(self.timestep_dimension).numpy().astype(np.float32))
+        handle = C.c_void_p()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(device):
+            check(_lib.lib().mtk_clf_create(index, self.num_timesteps, self.input_dimension, self.timestep_dimension, len(widths),
+                                            w32.ctypes.data, sl.ctypes.data, Wp, bp, fr.ctypes.data, _lib.stream_handle(device), C.byref(handle)))
+        self._handle, self._handle_key = handle, key
+        return handle
+
+    def _run(self, x: Tensor, timesteps: Tensor, y: Tensor | None, scale: float, want_logits: bool, want_grad: bool):
+        if not x.is_cuda:
+            raise RuntimeError("Classifier: midst_toolkit_amd has no CPU path; move the module and inputs to the MI355X")
+        if self.training:
+            raise NotImplementedError("the MI355X classifier path is the eval-mode network (BatchNorm running statistics, no Dropout), which "
+                                      "is how the synthesizer calls it (TRAIN:447); train the classifier with the reference's module and load its state dict")
+        dev = x.device
+        h = self._engine(dev)
+        xf = x.detach().float().contiguous()
+        B = xf.shape[0]
+        t = timesteps.to(dev, torch.int64).contiguous()
+        yy = y.to(dev, torch.int64).view(-1).contiguous() if y is not None else None
+        logits = torch.empty((B, self.output_dimension), dtype=torch.float32, device=dev) if want_logits else None
+        grad = torch.empty((B, self.input_dimension), dtype=torch.float32, device=dev) if want_grad else None
+        with torch.cuda.device(dev):
+            check(_lib.lib().mtk_clf_guidance(h, B, ptr(xf), xf.stride(0), ptr(t), ptr(yy), float(scale), ptr(logits), ptr(grad), _lib.stream_handle(dev)))
+        return logits, grad
+
+    def forward(self, input_tensor: Tensor, timesteps: Tensor) -> Tensor:
+        """MODEL:103-120 (eval mode): logits [B, output_dimension]."""
+        if torch.is_grad_enabled() and input_tensor.requires_grad:
+            raise NotImplementedError("Classifier.forward builds no autograd graph; use guidance_gradient / get_conditioning_function for "
+                                      "the input gradient (hand-written backward in libmtk_hip.so)")
+        return self._run(input_tensor, timesteps, None, 1.0, True, False)[0]
+
+    def guidance_gradient(self, features: Tensor, timesteps: Tensor, target: Tensor, scale: float = 1.0) -> Tensor:
+        """SYNTH:443-449: ``scale * d log_softmax(classifier(x, t))[range(B), target].sum() / d x`` ([B, input_dimension] fp32)."""
+        return self._run(features, timesteps, target, scale, False, True)[1]
+
+
+def get_conditioning_function(classifier: Classifier, classifier_scale: float):
+    """Drop-in for ``_get_conditioning_function`` (SYNTH:429-451): the callable ``conditional_sample`` / ``sample`` take."""
+
+    def conditioning_function(features: Tensor, timestep: Tensor, **kwargs: Any) -> Tensor:
+        assert "y" in kwargs and kwargs["y"] is not None, "The kwargs parameter `y` must be provided."
+        assert isinstance(kwargs["y"], Tensor), "The kwargs parameter `y` must be a Tensor."
+        x = features[:, 1:] if kwargs.get("remove_first_col", False) else features
+        return classifier.guidance_gradient(x, timestep, kwargs["y"], classifier_scale)
+
+    return conditioning_function

@@ -36,8 +36,9 @@ struct G2 {
     const float* bias;             // [grid.y * tile] or null
     const float* emb; int emb_ld;  // optional [T][emb_ld], gathered by tvec[m]
     const int64_t* tvec; int64_t rows_valid; int T;  // per-row timesteps are clamped into [0, T) (mtk_tclamp)
-    const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed where mask <= 0
+    const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed (times neg_slope) where mask <= 0
     int relu;
+    float neg_slope;               // 0: ReLU; > 0: LeakyReLU slope, forward (relu != 0) and backward (mask != null) alike
     int atomic;                    // accumulate with fp32 atomic add (split-K)
     float* rowsum;                 // optional [M]: += sum_k A[m][k] (the bias gradient rides in the wgrad GEMM: the waves of
                                    // column tile 0 sum the A fragments they hold anyway; atomics, like C under split-K)
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                     const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
                     v += g.emb[(int64_t)tr * g.emb_ld + n];
                 }
-                if (g.relu) v = fmaxf(v, 0.0f);
-                if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v : 0.0f;
+                if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v : g.neg_slope * v;
                 float* dst = g.C + row * g.c_rs + (int64_t)n * g.c_cs;
                 if (g.atomic) unsafeAtomicAdd(dst, v); else *dst = v;
             }
@@ -701,4 +702,261 @@ extern "C" int mtk_train_import(mtk_ctx* c, int image, const float* const* W, co
     MTK_HIP(hipGetLastError());
     if (image == 0) return refresh_emb(c, s);
     return MTK_OK;
+}
+
+// =================================================================================================================
+// Classifier guidance: the reference's `Classifier` (models/clavaddpm/model.py:45-120) in
+// eval mode and the input gradient its conditioning function takes through autograd
+// (models/clavaddpm/synthesizer.py:429-451): grad = scale * d log_softmax(classifier(x, t))[y] / d x.
+//
+// Network as the library sees it: h0 = proj(x) + emb[t] (emb = Linear(SiLU(Linear(sinusoid(t)))), a [T, dim_t] table
+// built here), then n_lin Linear layers, each but the last followed by ReLU (slope 0) or LeakyReLU (slope > 0).  The
+// reference's eval-mode BatchNorm1d after each activation is an affine map per feature; the host folds it into the
+// NEXT Linear (W' = W diag(s), b' = b + W o) before handing the weights over, and Dropout is the identity in eval mode.
+// Forward and the hand-written backward (softmax residual -> dgrad chain with activation masks -> proj^T) run on the
+// same fp32 MFMA GEMM as the training iteration above; nothing goes through autograd.
+// =================================================================================================================
+struct mtk_clf {
+    int device = 0, T = 0, D_in = 0, n_out = 0, dim_t = 0, n_lin = 0;
+    std::vector<float> slopes;      // activation after Linear i, i < n_lin - 1
+    MlpLayer proj;
+    std::vector<MlpLayer> lin;
+    float* emb = nullptr;           // [Tpad][emb_ld]
+    int emb_ld = 0;
+    // workspaces for `cap` rows (a multiple of 128)
+    int64_t cap = 0;
+    float* xin = nullptr;           // [cap][proj.in_pad]
+    std::vector<float*> act;        // act[0] = h0 [cap][proj.out_pad]; act[i + 1] = output of Linear i [cap][lin[i].out_pad]
+    float* d[2] = {nullptr, nullptr};  // gradient ping-pong [cap][widest padded layer]
+};
+
+namespace {
+
+__global__ void k_clf_pad_rows(float* dst, int ld, const float* src, int64_t src_ld, int64_t rows, int64_t rows_pad, int cols) {
+    const int64_t n = rows_pad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = (r < rows && c < cols) ? src[r * src_ld + c] : 0.0f;
+    }
+}
+// d log_softmax(logits)[y] / d logits = onehot(y) - softmax(logits), times `scale`; padding rows / columns zero.
+// One lane per row (n_out is the number of clusters: tens).
+__global__ __launch_bounds__(256) void k_clf_dlogits(const float* logits, int ld, int64_t rows, int64_t rows_pad, int n_out, const int64_t* y,
+                                                     float scale, float* dl) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows_pad; r += (int64_t)gridDim.x * 256) {
+        float* o = dl + r * ld;
+        if (r >= rows) {
+            for (int j = 0; j < ld; ++j) o[j] = 0.0f;
+            continue;
+        }
+        const float* z = logits + r * ld;
+        float mx = -INFINITY;
+        for (int j = 0; j < n_out; ++j) mx = fmaxf(mx, z[j]);
+        float sum = 0.0f;
+        for (int j = 0; j < n_out; ++j) sum += expf(z[j] - mx);
+        const float lse = mx + logf(sum);
+        const int64_t yy = y[r];
+        for (int j = 0; j < ld; ++j) o[j] = j < n_out ? scale * ((j == yy ? 1.0f : 0.0f) - expf(z[j] - lse)) : 0.0f;
+    }
+}
+__global__ void k_clf_copy_out(float* dst, int64_t dst_ld, const float* src, int ld, int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        dst[r * dst_ld + c] = src[r * ld + c];
+    }
+}
+
+void clf_free_layer(MlpLayer& l) {
+    if (l.w32) (void)hipFree(l.w32);
+    if (l.b32) (void)hipFree(l.b32);
+    l = MlpLayer();
+}
+int clf_make_layer(MlpLayer& l, int in, int out, int in_pad, const float* W, const float* b, hipStream_t s) {
+    l.in = in; l.out = out; l.in_pad = in_pad; l.out_pad = round_up(out, TN);
+    MTK_HIP(hipMalloc(&l.w32, sizeof(float) * (size_t)l.out_pad * l.in_pad));
+    MTK_HIP(hipMalloc(&l.b32, sizeof(float) * (size_t)l.out_pad));
+    MTK_HIP(hipMemsetAsync(l.w32, 0, sizeof(float) * (size_t)l.out_pad * l.in_pad, s));
+    MTK_HIP(hipMemsetAsync(l.b32, 0, sizeof(float) * (size_t)l.out_pad, s));
+    hipLaunchKernelGGL(k_pad, dim3(256), dim3(256), 0, s, l.w32, l.in_pad, W, out, in);
+    hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, l.b32, l.out_pad, b, 1, out);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+void clf_free_ws(mtk_clf* c) {
+    auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(c->xin); fr(c->d[0]); fr(c->d[1]);
+    for (auto& p : c->act) fr(p);
+    c->act.clear();
+    c->cap = 0;
+}
+int clf_ensure_ws(mtk_clf* c, int64_t Mpad, hipStream_t s) {
+    if (Mpad <= c->cap) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    clf_free_ws(c);
+    int maxpad = c->proj.out_pad > c->proj.in_pad ? c->proj.out_pad : c->proj.in_pad;
+    for (auto& l : c->lin) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
+    MTK_HIP(hipMalloc(&c->xin, sizeof(float) * (size_t)Mpad * c->proj.in_pad));
+    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&c->d[i], sizeof(float) * (size_t)Mpad * maxpad));
+    c->act.assign(1 + c->lin.size(), nullptr);
+    MTK_HIP(hipMalloc(&c->act[0], sizeof(float) * (size_t)Mpad * c->proj.out_pad));
+    for (size_t i = 0; i < c->lin.size(); ++i) MTK_HIP(hipMalloc(&c->act[1 + i], sizeof(float) * (size_t)Mpad * c->lin[i].out_pad));
+    c->cap = Mpad;
+    return MTK_OK;
+}
+
+}  // namespace
+
+extern "C" void mtk_clf_destroy(mtk_clf* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    clf_free_layer(c->proj);
+    for (auto& l : c->lin) clf_free_layer(l);
+    if (c->emb) (void)hipFree(c->emb);
+    clf_free_ws(c);
+    delete c;
+}
+
+extern "C" int mtk_clf_create(int device, int T, int D_in, int dim_t, int n_lin, const int32_t* widths_host, const float* slopes_host,
+                              const float* const* W, const float* const* b, const float* freqs_host, mtk_stream stream, mtk_clf** out) {
+    if (!out) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_create: out is null");
+    *out = nullptr;
+    if (T < 1 || D_in < 1 || dim_t < 2 || dim_t > 1024 || n_lin < 1 || n_lin > 32 || !widths_host || !W || !b || !freqs_host || (n_lin > 1 && !slopes_host))
+        MTK_FAIL(MTK_ERR_ARG, "mtk_clf_create: bad argument");
+    for (int i = 0; i < n_lin + 3; ++i)
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_create: W[%d] or b[%d] is null", i, i);
+    for (int i = 0; i < n_lin; ++i)
+        if (widths_host[i] < 1 || widths_host[i] > 8192) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_clf_create: layer width %d", widths_host[i]);
+    int n_dev = 0;
+    MTK_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_create: device %d of %d", device, n_dev);
+    MTK_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    mtk_clf* c = new mtk_clf();
+    c->device = device; c->T = T; c->D_in = D_in; c->dim_t = dim_t; c->n_lin = n_lin; c->n_out = widths_host[n_lin - 1];
+    for (int i = 0; i + 1 < n_lin; ++i) c->slopes.push_back(slopes_host[i]);
+    const int tp = round_up(dim_t, TN);
+    c->emb_ld = tp;
+    int rc = MTK_OK;
+    MlpLayer t0, t2;  // the time-embedding MLP, needed only to build the table
+    float *d_freq = nullptr, *sin_tab = nullptr, *z0 = nullptr, *e1 = nullptr;
+    auto fail = [&](int code) {
+        clf_free_layer(t0); clf_free_layer(t2);
+        if (d_freq) (void)hipFree(d_freq);
+        if (sin_tab) (void)hipFree(sin_tab);
+        if (z0) (void)hipFree(z0);
+        if (e1) (void)hipFree(e1);
+        mtk_clf_destroy(c);
+        return code;
+    };
+    // weight order: 0 proj, 1 timestep_embedding.0, 2 timestep_embedding.2, 3.. the n_lin Linear layers (BatchNorm folded in)
+    if ((rc = clf_make_layer(c->proj, D_in, dim_t, round_up(D_in, TN), W[0], b[0], s))) return fail(rc);  // in_pad = 128 k: the transposed-operand tiles of the final dgrad read whole 64/128-wide rows
+    if ((rc = clf_make_layer(t0, dim_t, dim_t, tp, W[1], b[1], s))) return fail(rc);
+    if ((rc = clf_make_layer(t2, dim_t, dim_t, tp, W[2], b[2], s))) return fail(rc);
+    c->lin.resize(n_lin);
+    int prev = dim_t, prev_pad = tp;
+    for (int i = 0; i < n_lin; ++i) {
+        if ((rc = clf_make_layer(c->lin[i], prev, widths_host[i], prev_pad, W[3 + i], b[3 + i], s))) return fail(rc);
+        prev = widths_host[i];
+        prev_pad = c->lin[i].out_pad;
+    }
+    const int Tpad = round_up(T, TM);
+    const size_t tb = sizeof(float) * (size_t)Tpad * tp;
+    hipError_t e = hipMalloc(&d_freq, sizeof(float) * (dim_t / 2));
+    if (e == hipSuccess) e = hipMalloc(&sin_tab, tb);
+    if (e == hipSuccess) e = hipMalloc(&z0, tb);
+    if (e == hipSuccess) e = hipMalloc(&e1, tb);
+    if (e == hipSuccess) e = hipMalloc(&c->emb, tb);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (dim_t / 2), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+        mtk_set_error("mtk_clf_create: %s", hipGetErrorString(e));
+        return fail(MTK_ERR_HIP);
+    }
+    hipLaunchKernelGGL(k_sin_tab, dim3(256), dim3(256), 0, s, sin_tab, Tpad, tp, T, dim_t, d_freq);
+    G2 g{};
+    g.M = Tpad; g.N = tp; g.K = tp; g.kchunk = tp;
+    g.A = sin_tab; g.lda = tp; g.B = t0.w32; g.ldb = tp; g.C = z0; g.c_rs = tp; g.c_cs = 1; g.bias = t0.b32;
+    if ((rc = launch<false, false>(g, s))) return fail(rc);
+    hipLaunchKernelGGL(k_silu, dim3(256), dim3(256), 0, s, z0, e1, (int64_t)Tpad * tp);
+    g.A = e1; g.B = t2.w32; g.C = c->emb; g.bias = t2.b32;
+    if ((rc = launch<false, false>(g, s))) return fail(rc);
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        mtk_set_error("mtk_clf_create: building the time-embedding table failed");
+        return fail(MTK_ERR_HIP);
+    }
+    clf_free_layer(t0); clf_free_layer(t2);
+    (void)hipFree(d_freq); (void)hipFree(sin_tab); (void)hipFree(z0); (void)hipFree(e1);
+    *out = c;
+    return MTK_OK;
+}
+
+// logits (optional, [B, n_out] row-major) and / or grad (optional, [B, D_in] row-major fp32):
+// grad = scale * d log_softmax(logits)[y] / d x.  x: [B, x_ld] row-major fp32; t: [B] int64 (clamped into [0, T) for
+// addressing; rows with a timestep outside it come back NaN); y: [B] int64 class indices (required with grad).
+extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,
+                                float* logits, float* grad, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_guidance: null classifier");
+    if (B < 0 || !x || !t || (grad && !y)) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_guidance: null pointer or negative B");
+    if (x_ld < c->D_in) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_guidance: x_ld %lld < input width %d", (long long)x_ld, c->D_in);
+    if (B == 0 || (!logits && !grad)) return MTK_OK;
+    if (B > (1 << 22)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_clf_guidance: B = %lld above 4194304 rows per call", (long long)B);
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    const int64_t Mpad = (B + TM - 1) / TM * TM;
+    int rc;
+    if ((rc = clf_ensure_ws(c, Mpad, s))) return rc;
+    hipLaunchKernelGGL(k_clf_pad_rows, dim3(1024), dim3(256), 0, s, c->xin, c->proj.in_pad, x, x_ld, B, Mpad, c->D_in);
+    {   // h0 = proj(x) + emb[t]   (MODEL:118-119)
+        G2 g{};
+        g.M = (int)Mpad; g.N = c->proj.out_pad; g.K = c->proj.in_pad; g.kchunk = g.K;
+        g.A = c->xin; g.lda = c->proj.in_pad; g.B = c->proj.w32; g.ldb = c->proj.in_pad;
+        g.C = c->act[0]; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
+        g.emb = c->emb; g.emb_ld = c->emb_ld; g.tvec = t; g.rows_valid = B; g.T = c->T;
+        if ((rc = launch<false, false>(g, s))) return rc;
+    }
+    for (int i = 0; i < c->n_lin; ++i) {   // MODEL:95-117 in eval mode
+        MlpLayer& l = c->lin[i];
+        G2 g{};
+        g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
+        g.A = c->act[i]; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
+        g.C = c->act[i + 1]; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32;
+        if (i + 1 < c->n_lin) { g.relu = 1; g.neg_slope = c->slopes[i]; }
+        if ((rc = launch<false, false>(g, s))) return rc;
+    }
+    const MlpLayer& last = c->lin.back();
+    if (logits) {
+        hipLaunchKernelGGL(k_clf_copy_out, dim3(1024), dim3(256), 0, s, logits, (int64_t)c->n_out, c->act.back(), last.out_pad, B, c->n_out);
+        if ((rc = mtk_poison_bad_t(t, B, c->T, logits, c->n_out, 1, c->n_out, nullptr, 0, 0, 0, nullptr, s))) return rc;
+    }
+    if (!grad) {
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
+    }
+    // SYNTH:446-449: selected = log_softmax(logits)[range, y]; grad of selected.sum() w.r.t. the input, times the scale
+    hipLaunchKernelGGL(k_clf_dlogits, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, s, c->act.back(), last.out_pad, B, Mpad, c->n_out, y,
+                       (float)scale, c->d[0]);
+    int cur = 0;
+    for (int i = c->n_lin - 1; i >= 0; --i) {
+        MlpLayer& l = c->lin[i];
+        G2 d{};
+        d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
+        d.A = c->d[cur]; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
+        d.C = c->d[cur ^ 1]; d.c_rs = l.in_pad; d.c_cs = 1;
+        if (i > 0) { d.mask = c->act[i]; d.m_rs = l.in_pad; d.neg_slope = c->slopes[i - 1]; }  // act[0] = h0 has no activation
+        if ((rc = launch<false, true>(d, s))) return rc;
+        cur ^= 1;
+    }
+    {   // d x = d h0 . W_proj
+        G2 d{};
+        d.M = (int)Mpad; d.N = c->proj.in_pad; d.K = c->proj.out_pad; d.kchunk = d.K;
+        d.A = c->d[cur]; d.lda = c->proj.out_pad; d.B = c->proj.w32; d.ldb = c->proj.in_pad;
+        d.C = c->d[cur ^ 1]; d.c_rs = c->proj.in_pad; d.c_cs = 1;
+        if ((rc = launch<false, true>(d, s))) return rc;
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_clf_copy_out, dim3(1024), dim3(256), 0, s, grad, (int64_t)c->D_in, c->d[cur], c->proj.in_pad, B, c->D_in);
+    MTK_HIP(hipGetLastError());
+    return mtk_poison_bad_t(t, B, c->T, grad, c->D_in, 1, c->D_in, nullptr, 0, 0, 0, nullptr, s);
 }

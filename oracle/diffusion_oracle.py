@@ -391,6 +391,38 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
     return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z
 
 
+# --------------------------------------------------------------------------- classifier guidance (section 8f rank 2)
+def classifier_logits(state: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, dim_t: int = 128) -> torch.Tensor:
+    """MODEL:103-120 in eval mode (how the synthesizer calls it, TRAIN:447): h0 = proj(x) + Linear(SiLU(Linear(sinusoid(t))));
+    then ``model`` = Linear, ReLU, BatchNorm1d (running statistics), Dropout (identity), [Linear, LeakyReLU, BatchNorm1d,
+    Dropout]*, Linear (MODEL:86-101).  ``state``: the reference classifier's state dict (transformer entries not needed)."""
+    emb = F.linear(F.silu(F.linear(timestep_embedding(t, dim_t), state["timestep_embedding.0.weight"], state["timestep_embedding.0.bias"])),
+                   state["timestep_embedding.2.weight"], state["timestep_embedding.2.bias"])
+    h = F.linear(x, state["proj.weight"], state["proj.bias"]) + emb
+    i, first = 0, True
+    while f"model.{i}.weight" in state:
+        h = F.linear(h, state[f"model.{i}.weight"], state[f"model.{i}.bias"])
+        if f"model.{i + 2}.running_mean" not in state:
+            break  # the output layer
+        h = F.relu(h) if first else F.leaky_relu(h)
+        h = F.batch_norm(h, state[f"model.{i + 2}.running_mean"], state[f"model.{i + 2}.running_var"], state[f"model.{i + 2}.weight"],
+                         state[f"model.{i + 2}.bias"], training=False, eps=1e-5)
+        i, first = i + 4, False
+    return h
+
+
+def classifier_conditioning_function(state: dict[str, torch.Tensor], scale: float):
+    """SYNTH:429-451: features -> scale * d log_softmax(classifier(features.float(), t))[range, y].sum() / d features."""
+    def conditioning_function(features, timestep, **kwargs):
+        y = kwargs["y"]
+        with torch.enable_grad():
+            xin = (features[:, 1:] if kwargs.get("remove_first_col", False) else features).detach().requires_grad_(True).float()
+            logp = F.log_softmax(classifier_logits(state, xin, timestep), dim=-1)
+            sel = logp[range(len(logp)), y.view(-1)]
+            return torch.autograd.grad(sel.sum(), xin)[0] * scale
+    return conditioning_function
+
+
 # --------------------------------------------------------------------------- DDIM (section 8f rank 4)
 def gaussian_ddim_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor, eta: float = 0.0):
     """GMD:1070-1118 (no conditioning): every table involved is fp32, so an fp32 state stays fp32."""

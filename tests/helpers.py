@@ -71,3 +71,17 @@ def load_ddim(tag: str) -> dict:
     d["S"] = int(d["K"].sum())
     d["D"] = d["Nn"] + d["S"]
     return d
+
+
+def load_classifier(tag: str = "A_numeric") -> dict:
+    """Fixture of tools/make_golden.py::gen_classifier: the reference's own Classifier (eval mode) and conditioning function."""
+    with np.load(os.path.join(GOLDEN, f"classifier_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    for k in ("Nn", "T", "n_classes"):
+        d[k] = int(d[k])
+    d["scale"] = float(d["scale"])
+    d["d_layers"] = [int(v) for v in d["d_layers"]]
+    d["hidden"] = [int(v) for v in d["hidden"]]
+    d["params"] = {k[2:]: tt(v) for k, v in d.items() if k.startswith("w_")}
+    d["state"] = {k[2:]: tt(v) for k, v in d.items() if k.startswith("c_")}
+    return d

@@ -1005,3 +1005,100 @@ def test_graph_replayed_chain_equals_eager_chain(tag, precision):
     d.use_graph = False
     x2, _ = d.sample_all(2 * B, B, torch.ones(1), seed=11)
     assert torch.equal(x2, x)
+
+
+def test_attack_feature_driver_reproduces_the_reference_loop():
+    """AttackFeatureDriver against the loop it replaces: for each model, for each timestep, for each
+    additional timestep, mixed_loss(...) -> x[:, count * P:(count + 1) * P] (TF:531-549).  Same kernels: identical features;
+    and against the reference's own scores of the N_tf fixture at the 1e-4 bar.  Models are ingested from state dicts."""
+    import midst_toolkit_amd as mtk
+    from midst_toolkit_amd import scoring
+
+    c = load_case("N_tf")
+    noise = tt(c["tf_noise"])
+    P = noise.shape[0]
+    pairs = [tuple(int(v) for v in c[f"tf{k}_t"]) for k in range(4)]       # (t, add) of the fixture's four calls
+    timesteps = sorted({t for t, a in pairs})
+    adds = sorted({a for t, a in pairs})
+    drv = mtk.AttackFeatureDriver(noise.tolist(), timesteps, adds, device=dev())
+    assert drv.feature_dimension == P * len(timesteps) * len(adds)
+    d0 = build(c)
+    sd = {k: v.detach().cpu() for k, v in d0.state_dict().items()}
+    ctor = {"num_classes": c["K"], "num_numerical_features": c["Nn"], "num_timesteps": c["T"], "scheduler_type": c["sched"]}
+    drv.add_model("m0", state_dict=sd, ctor_args=ctor)                      # ingested without any reference class
+    other = {k: (v * 1.01 if k.endswith("head.weight") else v) for k, v in sd.items()}
+    drv.add_model("m1", state_dict=other, ctor_args=ctor)
+    x0 = tt(c["x0"]).to(dev())
+    feats = drv.features("m0", x0)
+    assert feats.shape == (x0.shape[0], drv.feature_dimension) and feats.is_cuda
+    count = 0
+    for t in timesteps:                                                     # the reference's nest
+        for a in adds:
+            if t + a < c["T"]:
+                want = scoring.mixed_loss(d0, x0, {"y": None}, noise.tolist(), P, a, t)
+                assert torch.equal(feats[:, count * P:(count + 1) * P], want), (t, a)
+            count += 1
+    for k, (t, a) in enumerate(pairs):                                      # and the reference's own values
+        col = (timesteps.index(t) * len(adds) + adds.index(a)) * P
+        close(feats[:, col:col + P], tt(c[f"tf{k}_score"]), rtol=RTOL)
+    labels = torch.cat([torch.zeros(x0.shape[0] // 2), torch.ones(x0.shape[0] - x0.shape[0] // 2)])
+    x, y = drv.matrix([("m0", x0, labels), ("m1", x0, labels)])
+    assert x.shape == (2 * x0.shape[0], drv.feature_dimension) and y.shape == (2 * x0.shape[0],)
+    assert torch.equal(x[: x0.shape[0]], feats) and not torch.equal(x[x0.shape[0]:], feats)
+    # the matrix feeds a classifier of the reference's shape (classification.py: 3-layer tanh MLP) as is; challenge scoring
+    clf = torch.nn.Sequential(torch.nn.Linear(drv.feature_dimension, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1), torch.nn.Sigmoid())
+    pred = drv.challenge_predictions("m1", x0, clf)
+    assert pred.shape == (x0.shape[0], 1) and float(pred.min()) == 0.0 and float(pred.max()) == 1.0
+
+
+def test_classifier_guidance_on_hip():
+    """the reference's guidance classifier (MODEL:45-120, eval mode) and its conditioning function
+    (SYNTH:429-451) through mtk_clf_guidance, against the reference's own outputs (tests/golden/classifier_A_numeric.npz):
+    logits and gradients <= 1e-4 of their scale; then conditional_sample (GMD:1319) driven by the HIP conditioning function
+    against the reference's chain at the whole-chain bar."""
+    import midst_toolkit_amd as mtk
+    from tests.helpers import load_classifier
+
+    c = load_classifier()
+    clf = mtk.Classifier(c["Nn"], c["n_classes"], 128, c["hidden"], dropout_prob=0.1).to(dev())
+    clf.load_state_dict(c["state"], strict=True)
+    with pytest.raises(NotImplementedError):
+        clf.train()(torch.zeros((2, c["Nn"]), device=dev()), torch.zeros(2, dtype=torch.long, device=dev()))
+    clf.eval()
+    x, t, y = tt(c["x"]).to(dev()), tt(c["t"]).to(dev()), tt(c["y"]).to(dev())
+    with torch.no_grad():
+        logits = clf(x, t)
+    want = tt(c["logits"])
+    assert float((logits.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    cond = mtk.get_conditioning_function(clf, c["scale"])
+    g = cond(x.double(), t, y=y)
+    wg = tt(c["grad"])
+    assert g.shape == wg.shape and g.dtype == torch.float32
+    assert float((g.cpu() - wg).abs().max()) <= 1e-4 * float(wg.abs().max()), float((g.cpu() - wg).abs().max()) / float(wg.abs().max())
+    g2 = cond(tt(c["x_rfc"]).to(dev()), t, y=y, remove_first_col=True)
+    assert float((g2.cpu() - tt(c["grad_rfc"])).abs().max()) <= 1e-4 * float(wg.abs().max())
+    # out-of-range timesteps poison their rows, ragged batch sizes work
+    tb = t.clone()
+    tb[7] = 5000
+    gb = cond(x, tb, y=y)
+    assert bool(gb[7].isnan().all()) and torch.equal(torch.cat([gb[:7], gb[8:]]), torch.cat([g[:7], g[8:]]))
+    assert torch.equal(cond(x[:37], t[:37], y=y[:37]), g[:37])
+    # the chain: conditional_sample with the reference's draws injected
+    Nn, T = c["Nn"], c["T"]
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(c["d_layers"], 0.0))
+    net.load_state_dict(c["params"], strict=True)
+    d = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev()).to(dev())
+    targets = tt(c["targets"])
+    noise = [tt(n).to(dev()) for n in c["cs_noise"]]
+    noise[0] = noise[0].float()
+    inj = {"z0": tt(c["cs_z0"]).to(dev()), "noise": noise}
+    got, outs = d.conditional_sample(targets, model_kwargs={"y": targets.to(dev())}, conditioning_function=cond, _injected=inj)
+    want = tt(c["cs_sample"])
+    s = orc.make_schedule(T, "cosine")
+    ocond = orc.classifier_conditioning_function(c["state"], c["scale"])
+    ref64 = orc.sample_chain(s, np.array([0]), Nn, c["params"], inj["z0"].cpu(), None, [n.cpu() for n in noise], [None] * T, mlp_dtype=torch.float64,
+                             conditioning_function=ocond, model_kwargs={"y": targets})
+    own = float((ref64 - want).abs().max())
+    close(got, want, rtol=RTOL, atol=max(1e-5, 3 * own))
+    plain, _ = d.sample(targets.shape[0], torch.ones(3), _injected=dict(inj, y=torch.zeros(targets.shape[0], dtype=torch.long)))
+    assert float((plain - want).abs().max()) > 1e-2  # the guidance moved the chain

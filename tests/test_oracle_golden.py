@@ -181,3 +181,24 @@ def test_gaussian_kl_rows_bit_exact(tag):
         out = orc.mlp_forward(case_params(c), x_t, tc)
         mean = float(orc.gaussian_kl_rows(s, out, x0, x_t, tc).mean())
         assert abs(mean - float(k["call_means"][1])) <= 1e-6 * abs(float(k["call_means"][1]))
+
+
+def test_classifier_restatement_matches_the_reference_classifier():
+    """The oracle's eval-mode Classifier and conditioning function against the reference's own (classifier_A_numeric.npz,
+    generated by running MODEL:45-120 and SYNTH:429-451): logits, guidance gradients (plain and remove_first_col) and the
+    conditional_sample chain they drive."""
+    from tests.helpers import load_classifier
+
+    c = load_classifier()
+    x, t, y = tt(c["x"]), tt(c["t"]), tt(c["y"])
+    torch.testing.assert_close(orc.classifier_logits(c["state"], x, t), tt(c["logits"]), rtol=1e-6, atol=1e-6)
+    cond = orc.classifier_conditioning_function(c["state"], c["scale"])
+    torch.testing.assert_close(cond(x.double(), t, y=y), tt(c["grad"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(cond(tt(c["x_rfc"]), t, y=y, remove_first_col=True), tt(c["grad_rfc"]), rtol=1e-5, atol=1e-7)
+    s = orc.make_schedule(c["T"], "cosine")
+    targets = tt(c["targets"])
+    noise = [tt(n) for n in c["cs_noise"]]
+    noise[0] = noise[0].float()
+    got = orc.sample_chain(s, np.array([0]), c["Nn"], c["params"], tt(c["cs_z0"]), None, noise, [None] * c["T"], conditioning_function=cond,
+                           model_kwargs={"y": targets})
+    torch.testing.assert_close(got, tt(c["cs_sample"]), rtol=1e-6, atol=1e-6)

@@ -342,6 +342,57 @@ def gen_guided(tag, Nn, d_layers, T_chain, B, n_classes=3, scale=0.35):
     print(f"guided {tag}: B={B} Nn={Nn} T={T_chain}")
 
 
+def gen_classifier(tag="A_numeric", Nn=8, d_layers=(64, 64), T_chain=12, B=48, n_classes=5, hidden=(64, 128, 96), scale=1.5):
+    """The reference's own guidance classifier (MODEL:45-120) in eval mode, as the synthesizer uses it (TRAIN:447), through the
+    reference's own conditioning function (SYNTH:429-451): logits and guidance gradients on fixed inputs (per-row timesteps,
+    with and without remove_first_col), and conditional_sample (GMD:1319) driven by it with every draw captured.  BatchNorm
+    running statistics and affine parameters are randomised so that folding them is not a no-op.  The nn.Transformer the
+    reference constructs and never calls is left out of the stored state dict (4 M parameters)."""
+    from midst_toolkit.models.clavaddpm import synthesizer as synth
+
+    torch.manual_seed(4242)
+    clf = model.Classifier(input_dimension=Nn, output_dimension=n_classes, timestep_dimension=128, hidden_sizes=list(hidden), dropout_prob=0.1)
+    g = torch.Generator().manual_seed(17)
+    for m in clf.model:
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.3)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 1.5 + 0.25)
+            with torch.no_grad():
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+    clf.eval()
+    out = {"Nn": np.array(Nn), "d_layers": np.array(d_layers), "T": np.array(T_chain), "n_classes": np.array(n_classes),
+           "hidden": np.array(hidden), "scale": np.array(scale)}
+    out.update({f"c_{k}": v.numpy() for k, v in clf.state_dict().items() if not k.startswith("transformer_layer.")})
+    # ---- forward and guidance gradient on fixed inputs, per-row timesteps over the whole table
+    Bx = 200
+    x = torch.randn((Bx, Nn), generator=g) * 1.2
+    t = torch.randint(0, 1000, (Bx,), generator=g)
+    t[:3] = torch.tensor([0, 1, 999])
+    y = torch.randint(0, n_classes, (Bx, 1), generator=g)
+    with torch.no_grad():
+        logits = clf(x, t)
+    cond = synth._get_conditioning_function(clf, scale)
+    grad = cond(x.double(), t, y=y)                      # the chain hands fp64 features after the first step
+    x1 = torch.cat([torch.randn((Bx, 1), generator=g), x], 1)
+    grad_rfc = cond(x1, t, y=y, remove_first_col=True)
+    out.update(x=x.numpy(), t=t.numpy(), y=y.numpy(), logits=logits.numpy(), grad=grad.numpy(), x_rfc=x1.numpy(), grad_rfc=grad_rfc.numpy())
+    # ---- conditional_sample guided by the classifier
+    diff, params = build([0], Nn, list(d_layers), T_chain)
+    out.update({f"w_{k}": v.numpy() for k, v in params.items()})
+    targets = torch.randint(0, n_classes, (B, 1), generator=g)
+    log: list = []
+    torch.manual_seed(779)
+    with capture_rng(log):
+        with torch.no_grad():
+            smp, _ = diff.conditional_sample(targets, model_kwargs={"y": targets}, conditioning_function=cond)
+    kinds = [e[0] for e in log]
+    assert kinds == ["randn"] + ["randn_like"] * T_chain, kinds
+    out.update(targets=targets.numpy(), cs_z0=log[0][1].numpy(), cs_noise=np.stack([e[1].double().numpy() for e in log[1:]]), cs_sample=smp.numpy())
+    np.savez_compressed(os.path.join(OUT, f"classifier_{tag}.npz"), **out)
+    print(f"classifier {tag}: logits {tuple(logits.shape)} |grad| {float(grad.abs().mean()):.3e} sample {tuple(smp.shape)}")
+
+
 def gen_ddim(tag, K, Nn, d_layers, T_chain, B, sched="cosine"):
     """sample_ddim (GMD:1259) of the reference with every draw captured."""
     K = np.asarray(K, dtype=np.int64)
@@ -505,9 +556,13 @@ def main():
     if "--guided-only" in sys.argv:
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
         return
+    if "--classifier-only" in sys.argv:
+        gen_classifier()
+        return
     if "--train-only" not in sys.argv:
         main_cases()
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
+        gen_classifier()
         gen_loader()
         gen_quantile()
         gen_affine()
