@@ -260,6 +260,11 @@ int mtk_train_attach(mtk_ctx* ctx, float* state, const float* freqs_host, mtk_st
 int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
                    const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
                    uint64_t row0, mtk_stream stream);
+/* No reference counterpart beyond the reference pipeline's torch.use_deterministic_algorithms (common/random.py:11-55): on
+ * (default) = the split-batch reductions of the weight gradients are added in a fixed order (partial tiles in slabs) and the
+ * time-embedding scatter accumulates in 64-bit fixed point, so gradients are bit-identical run to run; off = fp32 hardware
+ * atomics (order varies). */
+int mtk_train_set_deterministic(mtk_ctx* ctx, int on);
 /* The two halves of mtk_train_step as separate calls: the autograd seam of the drop-in's mixed_loss (TRAINER:89-91 calls
  * mixed_loss and then .backward() on the sum of its two scalars; attacks/ensemble/clavaddpm_fine_tuning.py does the same).
  * mtk_train_forward = noising + denoiser forward with every activation kept + per-record losses.  mtk_train_backward fills

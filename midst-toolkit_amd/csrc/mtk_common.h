@@ -70,6 +70,14 @@ struct TrainState {
     std::vector<float*> act;       // act[0] = proj output, act[i] = block i output, row-major [cap][out_pad]
     float *out = nullptr, *dout = nullptr;  // column-major [Dpad128][cap]
     float* dact[2] = {nullptr, nullptr};   // row-major [cap][max_pad] gradient ping-pong
+    // deterministic reductions (default): split-K partial tiles / row sums land in slabs and are added in a fixed order;
+    // the time-embedding scatter accumulates in 64-bit fixed point.  false: fp32 hardware atomics (order varies run to run).
+    bool deterministic = true;
+    float* slab = nullptr;      // [splits][out_pad][in_pad] of the largest layer, sized with the activations
+    size_t slab_elems = 0;
+    float* slab_rs = nullptr;   // [splits][out_pad]
+    size_t slab_rs_elems = 0;
+    long long* demb_fix = nullptr;  // [Tpad][emb_ld] fixed-point accumulator of the time-embedding gradient
 };
 
 struct mtk_ctx {

@@ -42,6 +42,10 @@ struct G2 {
     int atomic;                    // accumulate with fp32 atomic add (split-K)
     float* rowsum;                 // optional [M]: += sum_k A[m][k] (the bias gradient rides in the wgrad GEMM: the waves of
                                    // column tile 0 sum the A fragments they hold anyway; atomics, like C under split-K)
+    // deterministic split-K: slice z of the reduction stores its partial tile (and row sums) to slab + z * slab_stride
+    // (rowsum_slab + z * M) with plain stores; k_reduce_splits then adds the slices in order.  Replaces the atomics.
+    float* slab; int64_t slab_stride;
+    float* rowsum_slab;
 };
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const bool sum_rows = g.rowsum != nullptr && blockIdx.y == 0 && wc == 0;  // wave-uniform
+    const bool sum_rows = (g.rowsum != nullptr || g.rowsum_slab != nullptr) && blockIdx.y == 0 && wc == 0;  // wave-uniform
     float rs[WT];
 #pragma unroll
     for (int a = 0; a < WT; ++a) rs[a] = 0.0f;
@@ -184,7 +188,10 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
 #pragma unroll
         for (int mt = 0; mt < WT; ++mt) {
             const float tot = rs[mt] + __shfl_xor(rs[mt], 32);
-            if (hh == 0) unsafeAtomicAdd(&g.rowsum[m0 + wr * 32 * WT + mt * 32 + li], tot);
+            if (hh == 0) {
+                if (g.rowsum_slab) g.rowsum_slab[(int64_t)blockIdx.z * g.M + m0 + wr * 32 * WT + mt * 32 + li] = tot;
+                else unsafeAtomicAdd(&g.rowsum[m0 + wr * 32 * WT + mt * 32 + li], tot);
+            }
         }
     }
 
@@ -206,8 +213,8 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 }
                 if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
                 if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v : g.neg_slope * v;
-                float* dst = g.C + row * g.c_rs + (int64_t)n * g.c_cs;
-                if (g.atomic) unsafeAtomicAdd(dst, v); else *dst = v;
+                float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
+                if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
             }
         }
 }
@@ -225,23 +232,6 @@ int launch(const G2& g, hipStream_t s) {
     return MTK_OK;
 }
 
-// bias gradient of a row-major dY [rows][ld]: column sums, rows split over blockIdx.y, atomic accumulate
-__global__ __launch_bounds__(256) void k_colsum_rm(const float* dy, int64_t ld, int64_t rows, int n, float* db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
-    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
-    // four independent partial sums: the loads of four rows are in flight together (one dependent chain per thread
-    // made this kernel latency-bound: 9 us for 8 MB)
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        const float v0 = dy[r * ld + c], v1 = dy[(r + 1) * ld + c], v2 = dy[(r + 2) * ld + c], v3 = dy[(r + 3) * ld + c];
-        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-    }
-    for (; r < r1; ++r) a0 += dy[r * ld + c];
-    unsafeAtomicAdd(&db[c], (a0 + a1) + (a2 + a3));
-}
 // bias gradient of a column-major dY [n][ld]: one workgroup per feature
 __global__ __launch_bounds__(256) void k_rowsum_cm(const float* dy, int64_t ld, int64_t rows, float* db) {
     __shared__ float part[256];
@@ -265,6 +255,50 @@ __global__ __launch_bounds__(256) void k_scatter_emb(const float* dact, int64_t 
         const float* src = dact + r * ld;
         for (int c = threadIdx.x; c < n; c += 64) unsafeAtomicAdd(&dst[c], src[c]);
     }
+}
+// dst[i] = sum over the `splits` slices of a slab region, slices added in index order (run-to-run identical), 4 floats per
+// thread; one launch serves every weight / bias gradient of the iteration (blockIdx.y = segment).
+constexpr int kMaxSegs = 48;
+struct ReduceSegs {
+    int n;
+    float* dst[kMaxSegs];
+    const float* slab[kMaxSegs];
+    int splits[kMaxSegs];
+    int64_t n4[kMaxSegs];  // floats / 4 per slice (= slice stride / 4)
+};
+__global__ __launch_bounds__(256) void k_reduce_splits(ReduceSegs r) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int sg = blockIdx.y;
+    const int64_t n4 = r.n4[sg];
+    const float* slab = r.slab[sg];
+    float* dst = r.dst[sg];
+    const int splits = r.splits[sg];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        v4f acc = *reinterpret_cast<const v4f*>(slab + 4 * i);
+        int z = 1;
+        for (; z + 8 <= splits; z += 8) {  // eight slices' loads in flight together, added in slice order
+            v4f v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const v4f*>(slab + ((int64_t)(z + j) * n4 + i) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; z < splits; ++z) acc += *reinterpret_cast<const v4f*>(slab + ((int64_t)z * n4 + i) * 4);
+        *reinterpret_cast<v4f*>(dst + 4 * i) = acc;
+    }
+}
+// Deterministic scatter-add of d act0 into the [T, dim_t] time-embedding gradient: 64-bit fixed-point integer atomics
+// (integer addition is associative, so the result does not depend on the order the rows arrive in), 2^-36 resolution.
+constexpr double kFixScale = 68719476736.0;  // 2^36: |sum| < 1.3e8, resolution 1.5e-11
+__global__ __launch_bounds__(256) void k_scatter_emb_fixed(const float* dact, int64_t ld, const int64_t* t, int64_t rows, int n, long long* acc, int emb_ld, int T) {
+    for (int64_t r = (int64_t)blockIdx.x * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.x * 4) {
+        long long* dst = acc + (int64_t)mtk_tclamp(t[r], T) * emb_ld;
+        const float* src = dact + r * ld;
+        for (int c = threadIdx.x; c < n; c += 64) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[c]), (unsigned long long)__double2ll_rn((double)src[c] * kFixScale));
+    }
+}
+__global__ void k_fixed_to_float(const long long* acc, float* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)((double)acc[i] / kFixScale);
 }
 __global__ void k_silu(const float* z, float* y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -345,10 +379,17 @@ std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
 
 void free_acts(TrainState& tr) {
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(tr.xin); fr(tr.xt_idx); fr(tr.out); fr(tr.dout); fr(tr.dact[0]); fr(tr.dact[1]);
+    fr(tr.xin); fr(tr.xt_idx); fr(tr.out); fr(tr.dout); fr(tr.dact[0]); fr(tr.dact[1]); fr(tr.slab); fr(tr.slab_rs);
+    tr.slab_elems = tr.slab_rs_elems = 0;
     for (auto& p : tr.act) fr(p);
     tr.act.clear();
     tr.cap = 0;
+}
+
+int kchunk_for(int64_t K, int tiles);
+int splits_for(int64_t K, int tiles) {
+    const int ch = kchunk_for(K, tiles);
+    return (int)((K + ch - 1) / ch);
 }
 
 int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
@@ -367,6 +408,23 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     tr.act.assign(1 + c->blocks.size(), nullptr);
     MTK_HIP(hipMalloc(&tr.act[0], sizeof(float) * (size_t)Mpad * c->proj.out_pad));
     for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act[1 + i], sizeof(float) * (size_t)Mpad * c->blocks[i].out_pad));
+    // split-K slabs of the weight-gradient GEMMs (deterministic reductions): every layer has its own region (splits x
+    // layer), so that ONE reduction kernel at the end of the backward pass adds all of them
+    size_t need = 0, need_rs = 0;
+    auto account = [&](const MlpLayer& l, int64_t K) {
+        const int sp = splits_for(K, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
+        need += (size_t)sp * l.out_pad * l.in_pad;
+        need_rs += (size_t)sp * l.out_pad;
+    };
+    account(c->proj, Mpad);
+    account(c->head, Mpad);
+    for (auto& l : c->blocks) account(l, Mpad);
+    account(c->temb0, tr.Tpad);
+    account(c->temb2, tr.Tpad);
+    MTK_HIP(hipMalloc(&tr.slab, sizeof(float) * need));
+    MTK_HIP(hipMalloc(&tr.slab_rs, sizeof(float) * need_rs));
+    tr.slab_elems = need;
+    tr.slab_rs_elems = need_rs;
     tr.cap = Mpad;
     return MTK_OK;
 }
@@ -408,6 +466,8 @@ void mtk_free_train(mtk_ctx* c) {
     TrainState& tr = c->train;
     auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(tr.sin_tab); fr(tr.z0_tab); fr(tr.e1_tab); fr(tr.demb); fr(tr.dtab);
+    if (tr.demb_fix) (void)hipFree(tr.demb_fix);
+    tr.demb_fix = nullptr;
     free_acts(tr);
     tr.layers.clear();
     tr.attached = false;
@@ -470,6 +530,7 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     MTK_HIP(hipMalloc(&tr.e1_tab, tb));
     MTK_HIP(hipMalloc(&tr.demb, tb));
     MTK_HIP(hipMalloc(&tr.dtab, tb));
+    MTK_HIP(hipMalloc(&tr.demb_fix, sizeof(long long) * (size_t)tr.Tpad * tp));
     float* d_freq = nullptr;
     MTK_HIP(hipMalloc(&d_freq, sizeof(float) * (c->dim_t / 2)));
     MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (c->dim_t / 2), hipMemcpyHostToDevice, s));
@@ -556,14 +617,39 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         for (auto& r : tr.layers) if (r.l == l) return r;
         return tr.layers[0];
     };
+    // weight-gradient GEMM, split-K over the batch: deterministic (partial tiles to slabs, added in order) or fp32 atomics
+    ReduceSegs segs;
+    segs.n = 0;
+    size_t slab_used = 0, slab_rs_used = 0;
+    auto wgrad = [&](G2& g, auto launcher, float* dw, float* db) -> int {
+        const int splits = (g.K + g.kchunk - 1) / g.kchunk;
+        const size_t elems = (size_t)g.M * g.N;
+        if (!tr.deterministic) {
+            g.C = dw; g.atomic = 1; g.rowsum = db;
+            return launcher(g);
+        }
+        if (slab_used + (size_t)splits * elems > tr.slab_elems || slab_rs_used + (size_t)splits * g.M > tr.slab_rs_elems || segs.n + 2 > kMaxSegs)
+            MTK_FAIL(MTK_ERR_STATE, "mtk_train_step: split-K slab too small (%d x %zu)", splits, elems);
+        g.C = dw; g.atomic = 0; g.rowsum = nullptr;
+        g.slab = tr.slab + slab_used; g.slab_stride = (int64_t)elems; g.rowsum_slab = db ? tr.slab_rs + slab_rs_used : nullptr;
+        segs.dst[segs.n] = dw; segs.slab[segs.n] = g.slab; segs.splits[segs.n] = splits; segs.n4[segs.n] = (int64_t)elems / 4;
+        ++segs.n;
+        slab_used += (size_t)splits * elems;
+        if (db) {
+            segs.dst[segs.n] = db; segs.slab[segs.n] = g.rowsum_slab; segs.splits[segs.n] = splits; segs.n4[segs.n] = (int64_t)g.M / 4;
+            ++segs.n;
+            slab_rs_used += (size_t)splits * g.M;
+        }
+        return launcher(g);
+    };
     {   // head: dW[o][k] = sum_m dout[o][m] act[m][k];  db = row sums;  d act = dout^T W  masked by act > 0
         MlpLayer& l = c->head;
         TrainLayerRef& r = ref_of(&l);
         G2 g{};
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = tr.dout; g.lda = ld; g.B = tr.act.back(); g.ldb = l.in_pad;
-        g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
-        if ((rc = launch<false, true>(g, s))) return rc;
+        g.c_rs = l.in_pad; g.c_cs = 1;
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<false, true>(q, s); }, grads + r.w_off, nullptr))) return rc;
         hipLaunchKernelGGL(k_rowsum_cm, dim3(l.out), dim3(256), 0, s, tr.dout, ld, Mpad, grads + r.b_off);
         G2 d{};
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
@@ -580,9 +666,9 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         G2 g{};
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = dy; g.lda = l.out_pad; g.B = tr.act[i]; g.ldb = l.in_pad;
-        g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
-        g.rowsum = grads + r.b_off;  // db[o] = sum_m dy[m][o]
-        if ((rc = launch<true, true>(g, s))) return rc;
+        g.c_rs = l.in_pad; g.c_cs = 1;
+        // db[o] = sum_m dy[m][o] rides along
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
         G2 d{};
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
@@ -598,10 +684,16 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         G2 g{};
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
-        g.C = grads + r.w_off; g.c_rs = l.in_pad; g.c_cs = 1; g.atomic = 1;
-        g.rowsum = grads + r.b_off;
-        if ((rc = launch<true, false>(g, s))) return rc;
-        hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
+        g.c_rs = l.in_pad; g.c_cs = 1;
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if (tr.deterministic) {
+            const int64_t ne = (int64_t)tr.Tpad * c->emb_ld;
+            MTK_HIP(hipMemsetAsync(tr.demb_fix, 0, sizeof(long long) * (size_t)ne, s));
+            hipLaunchKernelGGL(k_scatter_emb_fixed, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
+            hipLaunchKernelGGL(k_fixed_to_float, dim3(256), dim3(256), 0, s, tr.demb_fix, tr.demb, ne);
+        } else {
+            hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
+        }
     }
     {   // time-embedding MLP over the T-row table
         const int tp = c->emb_ld;
@@ -609,19 +701,27 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         TrainLayerRef &r2 = ref_of(&l2), &r0 = ref_of(&l0);
         G2 g{};
         g.M = tp; g.N = tp; g.K = tr.Tpad; g.kchunk = kchunk_for(tr.Tpad, (tp / TM) * (tp / TN));
-        g.A = tr.demb; g.lda = tp; g.B = tr.e1_tab; g.ldb = tp; g.C = grads + r2.w_off; g.c_rs = tp; g.c_cs = 1; g.atomic = 1;
-        if ((rc = launch<true, true>(g, s))) return rc;
-        hipLaunchKernelGGL(k_colsum_rm, dim3((tp + 255) / 256, 16), dim3(256), 0, s, tr.demb, (int64_t)tp, (int64_t)tr.Tpad, tp, grads + r2.b_off);
+        g.A = tr.demb; g.lda = tp; g.B = tr.e1_tab; g.ldb = tp; g.c_rs = tp; g.c_cs = 1;
+        // the bias gradients (column sums of demb / dtab) ride in the GEMMs as the row sums of their transposed A operand
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r2.w_off, grads + r2.b_off))) return rc;
         G2 d{};
         d.M = tr.Tpad; d.N = tp; d.K = tp; d.kchunk = tp;
         d.A = tr.demb; d.lda = tp; d.B = l2.w32; d.ldb = tp; d.C = tr.dtab; d.c_rs = tp; d.c_cs = 1;
         if ((rc = launch<false, true>(d, s))) return rc;
         hipLaunchKernelGGL(k_silu_bwd, dim3(256), dim3(256), 0, s, tr.z0_tab, tr.dtab, (int64_t)tr.Tpad * tp);
-        g.A = tr.dtab; g.B = tr.sin_tab; g.C = grads + r0.w_off;
-        if ((rc = launch<true, true>(g, s))) return rc;
-        hipLaunchKernelGGL(k_colsum_rm, dim3((tp + 255) / 256, 16), dim3(256), 0, s, tr.dtab, (int64_t)tp, (int64_t)tr.Tpad, tp, grads + r0.b_off);
+        g.A = tr.dtab; g.B = tr.sin_tab;
+        g.slab = nullptr; g.rowsum_slab = nullptr;
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r0.w_off, grads + r0.b_off))) return rc;
     }
+    if (segs.n > 0)  // every split-batch partial of the iteration, added in slice order by one launch
+        hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)segs.n), dim3(256), 0, s, segs);
     MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_deterministic(mtk_ctx* c, int on) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_deterministic: null context");
+    c->train.deterministic = on != 0;
     return MTK_OK;
 }
 

@@ -216,6 +216,10 @@ class Engine:
             check(_lib.lib().mtk_train_step(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), float(inv_global_batch),
                                             ptr(loss_multi), ptr(loss_gauss), seed, row0, self._stream()))
 
+    def train_set_deterministic(self, on: bool) -> None:
+        """True (default): fixed-order reductions, gradients bit-identical run to run; False: fp32 hardware atomics."""
+        check(_lib.lib().mtk_train_set_deterministic(self._h, int(bool(on))))
+
     def train_forward(self, x0, t, eps, u, loss_multi=None, loss_gauss=None, seed=0, row0=0) -> int:
         """Forward half of train_step (activations kept on the context).  Returns a token that train_backward checks."""
         B = x0.shape[0]

@@ -66,7 +66,9 @@ def big_batch(c, B, seed=5):
 
 
 @pytest.mark.parametrize("tag,B,layers", [("B_ragged", 24, None), ("A_numeric", 24, None), ("B_ragged", 1000, [256, 128, 256]),
-                                          ("M", 4096, [512] * 4), ("M", 16384, [1024, 1024])])  # the last: 128 x 128 tiles in wgrad too
+                                          ("M", 4096, [512] * 4), ("M", 16384, [1024, 1024]),  # 128 x 128 tiles in wgrad too
+                                          ("M", 16384, [1024] * 4),  # BASELINE configs[4]: 4 x 1024, global batch 16,384
+                                          ("M", 2048, [1024] * 4)])  # ... and the 2,048 rows one of 8 ranks sees
 def test_gradients_match_autograd(tag, B, layers):
     if tag == "M":
         c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=layers)
@@ -96,6 +98,28 @@ def test_gradients_match_autograd(tag, B, layers):
         num = float((got[k].double() - want[k].double()).norm())
         den = float(want[k].double().norm())
         assert num <= 2e-4 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+
+
+@pytest.mark.parametrize("B,layers", [(4096, [512] * 4), (1000, [256, 128, 256])])
+def test_gradients_are_bit_identical_run_to_run(B, layers):
+    """The reference pipeline runs with torch.use_deterministic_algorithms (common/random.py:11-55).  Default mode here:
+    split-batch reductions added in a fixed order, the time-embedding scatter in fixed point - the same batch gives the
+    same gradient image bit for bit, call after call.  (The fp32-atomics mode stays available and within the parity bar.)"""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=layers)
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    x0, t, eps, u = [v.to(dev()) for v in big_batch(c, B)]
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    runs = []
+    for rep in range(3):
+        eng.train_step(x0, t, eps, u, 1.0 / B, None, None)
+        runs.append(tr.state[1].clone())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    eng.train_set_deterministic(False)
+    eng.train_step(x0, t, eps, u, 1.0 / B, None, None)
+    atomics = tr.state[1].clone()
+    rel = float((atomics - runs[0]).norm() / runs[0].norm())
+    assert rel < 1e-5, rel  # same sums, another order
 
 
 def test_adamw_ema_kernel():
