@@ -539,13 +539,14 @@ def ema_update(ema: dict[str, torch.Tensor], params: dict[str, torch.Tensor], ra
 
 
 def train_loop(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], batches, lr0: float, wd: float, steps: int):
-    """TRAINER:96-135 on pre-drawn batches ``[(x0, t, eps, u)]``: returns (per-step [lm, lg], final params, EMA)."""
+    """TRAINER:96-135 on pre-drawn batches ``[(x0, t, eps, u)]``: returns (per-step [lm, lg], final params, EMA).
+    ``steps`` is the run's length (the annealing horizon); fewer batches run only the head of it."""
     p = {k: v.detach().clone() for k, v in params.items()}
     ema = {k: v.clone() for k, v in p.items()}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v2 = {k: torch.zeros_like(v) for k, v in p.items()}
     lr, hist = lr0, []
-    for step in range(steps):
+    for step in range(min(steps, len(batches))):
         x0, t, eps, u = batches[step]
         g, lm, lg = loss_and_grads(s, K, Nn, p, x0, t, eps, u)
         for k in p:

@@ -296,6 +296,63 @@ def gen_train(tag, K, Nn, d_layers, T, B, steps, lr, wd, n_rows=99):
     print(f"train {tag}: losses {losses[0]} -> {losses[-1]}")
 
 
+def gen_train_berka(steps=200, B=24, lr=6e-4, wd=1e-5):
+    """BASELINE configs[0] / SURVEY 8c: the reference trainer for 200 iterations on the Berka 'trans' subset the reference's own
+    integration test trains on (tests/integration/assets/single_table/train.csv, 99 rows x 8 columns, all in the numeric block
+    as the shipped pipeline puts them), normalised by the reference's `normalize` (QuantileTransformer, output normal), with
+    the test's denoiser [512, 1024, 1024, 1024, 1024, 512], T = 1000, batch 24.  Stored: the already-transformed matrix, the
+    batch order, every draw, the two loss means per iteration, and - the trained image is 4.7 M parameters - a strided
+    sample (every 997th entry) of the trained and EMA weights."""
+    import importlib
+
+    import pandas as pd
+    from midst_toolkit.common.dataset_transformations import normalize
+    from midst_toolkit.common.enumerations import DataSplit, Normalization
+
+    trainer_mod = importlib.import_module("midst_toolkit.models.clavaddpm.trainer")
+    raw = pd.read_csv("/root/reference/tests/integration/assets/single_table/train.csv").to_numpy(dtype=np.float64)
+    data, _ = normalize({DataSplit.TRAIN.value: raw}, Normalization.QUANTILE, seed=0)
+    table = torch.from_numpy(data[DataSplit.TRAIN.value].astype(np.float32))
+    n_rows, Nn = table.shape
+    d_layers = [512, 1024, 1024, 1024, 1024, 512]
+    g = torch.Generator().manual_seed(778)
+    diff, params = build([0], Nn, d_layers, 1000)
+    diff.train()
+    order = [torch.randint(0, n_rows, (B,), generator=g) for _ in range(steps)]
+
+    def batches():
+        for idx in order:
+            yield table[idx], torch.zeros(B, dtype=torch.long)
+
+    tr = trainer_mod.ClavaDDPMTrainer(diff, batches(), lr, wd, steps, device=CPU)
+    losses, draws = [], []
+    inner = tr._train_step
+
+    def spy(x, y):
+        log: list = []
+        with capture_rng(log):
+            lm, lg = inner(x, y)
+        losses.append([float(lm), float(lg)])
+        draws.append(log)
+        return lm, lg
+
+    tr._train_step = spy
+    torch.manual_seed(100)
+    tr.train()
+    ts = np.stack([log[0][1].numpy() for log in draws])
+    epss = np.stack([log[1][1].numpy() for log in draws])
+    assert all(len(log) == 2 and log[0][0] == "randint" and log[1][0] == "randn_like" for log in draws)
+    names = orc.mlp_param_names(len(d_layers))
+    sd, ema_sd = diff._denoise_fn.state_dict(), tr.ema_model.state_dict()
+    flat = lambda d: np.concatenate([np.concatenate([d[n + ".weight"].detach().numpy().ravel(), d[n + ".bias"].detach().numpy().ravel()]) for n in names])
+    np.savez_compressed(
+        os.path.join(OUT, "train_berka.npz"), K=np.array([0]), Nn=Nn, d_layers=np.asarray(d_layers), T=1000, sched="cosine", lr=lr, wd=wd, steps=steps,
+        table=table.numpy(), order=np.stack([o.numpy() for o in order]), t=ts, eps=epss, losses=np.asarray(losses, dtype=np.float64),
+        stride=997, final_sample=flat(sd)[::997].astype(np.float32), ema_sample=flat(ema_sd)[::997].astype(np.float32),
+        init_sample=flat(params)[::997].astype(np.float32))
+    print(f"train berka: {n_rows} x {Nn}, losses {losses[0]} -> {np.mean([l[1] for l in losses[-20:]]):.4f} (mean of the last 20)")
+
+
 def guidance_function(centers: torch.Tensor, scale: float, T: int):
     """A closed-form stand-in for the classifier gradient of SYNTH:429-451 (same call signature and dtype): the
     gradient of log N(features; centers[y], I) scaled by a factor that grows with t."""
@@ -559,6 +616,9 @@ def main():
     if "--classifier-only" in sys.argv:
         gen_classifier()
         return
+    if "--berka-only" in sys.argv:
+        gen_train_berka()
+        return
     if "--train-only" not in sys.argv:
         main_cases()
         gen_guided("A_numeric", 8, [64, 64], 12, 48)
@@ -573,6 +633,7 @@ def main():
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
+    gen_train_berka()
 
 
 def main_cases():
