@@ -707,6 +707,94 @@ def test_tf_score_bf16():
     assert float(((big - ref).abs() / ref.abs()).max()) <= BF16_TOL
 
 
+def _trained_shape_n(steps=600, batch=4096, n_members=2_000, n_total=100_000):
+    """A briefly trained 4x512 / 20-feature denoiser (BASELINE configs[1]'s shape) on 2,000 draws of a two-component Gaussian
+    mixture (~1,200 epochs, enough to start memorising them), and 100k records to score: the 2,000 training members first,
+    then fresh draws of the same mixture."""
+    import midst_toolkit_amd as mtk
+
+    Nn, T = 20, 1000
+    g = torch.Generator().manual_seed(20250821)
+
+    def draw(n):
+        comp = (torch.rand((n, 1), generator=g) < 0.35).float()
+        return (torch.randn((n, Nn), generator=g) * (0.4 + 0.5 * comp) + (2.0 * comp - 0.7)).clamp(-5.2, 5.2)
+
+    members, others = draw(n_members), draw(n_total - n_members)
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([512] * 4, 0.0))
+    diff = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev()).to(dev())
+    tr = mtk.ClavaDDPMTrainer(diff, iter(()), 1e-3, 0.0, steps, device=dev())
+    xm = members.to(dev())
+    for step in range(steps):
+        idx = torch.randint(0, n_members, (batch,), generator=g).to(dev())
+        tr._train_step(xm[idx], None)
+        tr._anneal_learning_rate(step)
+    tr.sync_modules()
+    tr.finish()
+    return diff, torch.cat([members, others]).to(dev()), torch.randn((4, Nn), generator=g).to(dev()), n_members
+
+
+def test_bf16_ranking_fidelity():
+    """What the bf16 tolerance means for the attack (north_star: membership-score rankings).  The headline
+    precision does not reproduce the fp32 ranking position by position - no 8-bit-mantissa product can - so the stated
+    tolerance is on what the attack consumes: rank correlation with the exact path, the top-decile membership set, and the
+    guarantee that two records only come out swapped when their fp32 scores are closer than the two score errors combined.
+    Measured on (a) the reference's own scores of the N_tf fixture, (b) 100k records under a random-init 4x512 denoiser and
+    (c) 100k records (half of them training members) under a briefly trained one; DESIGN section 4 quotes the figures
+    printed here.  The bf16x3 mode on the same inputs must give the fp32 ranking except inside documented ties."""
+    import midst_toolkit_amd as mtk
+    from midst_toolkit_amd import scoring
+
+    def bars(rep, rel, kendall, spearman, top, rel_bar=BF16_TOL):
+        assert rel <= rel_bar, rel
+        assert rep["worst_swapped_gap"] <= 2.2 * rel, rep  # a swap needs |want_i - want_j| <= err_i + err_j
+        assert rep["kendall"] >= kendall and rep["spearman"] >= spearman and rep["top10_overlap"] >= top, rep
+
+    c = load_case("N_tf")
+    d = build(c, precision="bf16")
+    x0, noise = tt(c["x0"]).to(dev()), tt(c["tf_noise"]).to(dev())
+    for k in (0, 1, 3):
+        t = int(c[f"tf{k}_t"][0])
+        got, want = scoring.score_records(d, x0, noise, [t], 0, precision="bf16")[0], tt(c[f"tf{k}_score"])
+        rep, rel = ranking_report(got, want), float(((got.cpu() - want).abs() / want.abs()).max())
+        print(f"bf16 ranking, N_tf fixture vs reference, t={t}: max rel err {rel:.2e}", rep)
+        bars(rep, rel, 0.97, 0.995, 0.9)
+
+    Nn, T, B, P = 20, 1000, 100_000, 4
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([512] * 4, 0.0))
+    rnd = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev()).to(dev())
+    g = torch.Generator().manual_seed(20250821)
+    x, nz = torch.randn((B, Nn), generator=g).clamp(-5.2, 5.2).to(dev()), torch.randn((P, Nn), generator=g).to(dev())
+    trained, xt, nzt, n_mem = _trained_shape_n()
+    ts = [5, 50, 200, 500, 900]
+    # a trained denoiser's scores are small residuals (eps - prediction)^2, so the same bf16 error of the prediction is a larger
+    # fraction of them (measured: up to 1.2e-1 of a score at t = 900, where the residual is smallest): no per-score bar is
+    # claimed for bf16 there, only the ranking bars and the member / non-member separation; bf16x3 keeps <= 1e-4 per score
+    for name, diff, rec, eps, (kendall, spearman, top, rel_bar) in (("random-init", rnd, x, nz, (0.97, 0.998, 0.95, BF16_TOL)),
+                                                                     ("trained", trained, xt, nzt, (0.96, 0.995, 0.95, float("inf")))):
+        ref = scoring.score_records(diff, rec, eps, ts, 0, precision="fp32")
+        got = scoring.score_records(diff, rec, eps, ts, 0, precision="bf16")
+        x3 = scoring.score_records(diff, rec, eps, ts, 0, precision="bf16x3")
+        for j, t in enumerate(ts):
+            rep, rel = ranking_report(got[j], ref[j]), float(((got[j] - ref[j]).abs() / ref[j].abs()).max())
+            print(f"bf16 ranking, 100k records, {name} 4x512, t={t}: median score {float(ref[j].median()):.3e}, max rel err {rel:.2e}", rep)
+            bars(rep, rel, kendall, spearman, top, rel_bar)
+            rep3, rel3 = ranking_report(x3[j], ref[j]), float(((x3[j] - ref[j]).abs() / ref[j].abs()).max())
+            print(f"bf16x3 ranking, 100k records, {name} 4x512, t={t}: max rel err {rel3:.2e}", rep3)
+            # trained: a score is a squared residual ~1e-2 of the eps scale, so fp32 summation-order noise of the prediction
+            # (~5e-7, present between any two fp32 implementations) is already up to ~2e-4 of the smallest scores
+            assert rel3 <= (RTOL if name == "random-init" else 1e-3) and rep3["worst_swapped_gap"] <= 2.2 * rel3 and rep3["kendall"] >= 0.9999, (rel3, rep3)
+        if name == "trained":  # the attack's signal: members score lower than non-members; bf16 must keep that separation
+            im = torch.randint(0, n_mem, (400_000,), generator=g).to(dev())
+            io = torch.randint(n_mem, rec.shape[0], (400_000,), generator=g).to(dev())
+            for j, t in enumerate(ts):
+                auc = [float((s_.mean(1)[im] < s_.mean(1)[io]).float().mean()) for s_ in (ref[j], got[j])]
+                print(f"member-vs-other pair AUC at t={t}: fp32 {auc[0]:.4f}, bf16 {auc[1]:.4f}")
+                assert abs(auc[0] - auc[1]) <= 2e-3, auc
+
+
 def test_mixed_loss_bf16_mean():
     c = load_case("M_mixed")
     d = build(c, precision="bf16")
