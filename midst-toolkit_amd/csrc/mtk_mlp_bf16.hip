@@ -253,6 +253,83 @@ __device__ __forceinline__ void dense(PIPE& p, bf16x8 (&w0)[kGrp], bf16x8 (&w1)[
     });
 }
 
+// ---- Tile-major layers (128 -> H and H -> H).  Fragment g of the layer multiplies k-step g % KS into tile g / KS: ONE
+// accumulator tile is busy at a time (a dependent chain of 32x32x16 MFMAs issues back to back), and two of them alternate.
+// While tile nt accumulates, the epilogue of tile nt - 1 (ReLU, cvt to bf16) rides in its MFMA gaps, a pair of values at a
+// time, followed by the bias of tile nt + 1 into the accumulator that epilogue just freed.  Nothing of a layer's
+// epilogue is exposed: the last tile's is still pending when the layer ends (PENDING) and rides under the first steps
+// of whatever comes next (the next layer's tile 0 or the head).
+//   Activations ping-pong without a second layer body: a layer reads its input from Xb and writes its output there.
+// Tile nt's output replaces k-steps 2nt, 2nt+1, which later tiles still need, so tile nt copies those two k-steps to Xa
+// (in its gaps) before tile nt + 1 overwrites them, and a tile reads k-steps < 2 nt from Xa, the others from Xb.
+template <int KS>
+__device__ __forceinline__ constexpr int epi_first(int ks) {  // first epilogue part (of 8) issued after the MFMA of step ks
+    if (KS == 32) {
+        constexpr int tab[32] = {-1, -1, 0, 1, 2, -1, 3, 4, 5, -1, 6, 7, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+        return tab[ks];
+    }
+    return (ks >= 2 && ks <= 5) ? 2 * (ks - 2) : -1;  // KS == 8: two parts per step
+}
+template <int KS>
+__device__ __forceinline__ constexpr int epi_count(int ks) { return epi_first<KS>(ks) < 0 ? 0 : (KS == 32 ? 1 : 2); }
+template <int KS>
+__device__ __forceinline__ constexpr int bias_first(int ks) {  // first 16-byte piece (of 4) of the next tile's bias
+    if (KS == 32) return ks == 15 ? 0 : ks == 16 ? 1 : ks == 18 ? 2 : ks == 19 ? 3 : -1;
+    return ks == 6 ? 0 : -1;
+}
+template <int KS>
+__device__ __forceinline__ constexpr int bias_count(int ks) { return bias_first<KS>(ks) < 0 ? 0 : (KS == 32 ? 1 : 4); }
+
+// epilogue part q of a finished tile held in `a`: values 2q, 2q+1 -> one packed bf16 pair (one dword) of the tile's two
+// k-steps.  The conversion is volatile asm: as plain C++ the compiler parks the ReLU'd fp32 values in spare registers and
+// sinks all of a layer's conversions to the layer's end (120 v_cvt_pk in a row, exposed).  ReLU on the packed pair: a
+// negative bf16 is a negative 16-bit integer.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int Q>
+__device__ __forceinline__ void epi_part(const f32x16& a, u32x4& lo, u32x4& hi) {
+    unsigned pk;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(pk) : "v"(a[2 * Q]), "v"(a[2 * Q + 1]));
+    if constexpr (Q < 4) lo[Q] = pk;
+    else hi[Q - 4] = pk;
+}
+template <int R>
+__device__ __forceinline__ void bias_piece(f32x16& a, unsigned base, int elem) {
+    const f32x4_t t = *(lds_f4*)(uintptr_t)(base + 4u * (unsigned)(elem + 8 * R));
+    a[4 * R] = t.x; a[4 * R + 1] = t.y; a[4 * R + 2] = t.z; a[4 * R + 3] = t.w;
+}
+
+// the pending epilogue of tile PT (held in `a`), as far as step ks of a KS-step tile carries it
+template <int KS, int KSTEP, int PT, int NX>
+__device__ __forceinline__ void epi_at(const f32x16& a, u32x4 (&Xb)[NX]) {
+    constexpr int q0 = epi_first<KS>(KSTEP), n = epi_count<KS>(KSTEP);
+    static_for<n>([&](auto qc) { epi_part<q0 + decltype(qc)::value>(a, Xb[2 * PT], Xb[2 * PT + 1]); });
+}
+
+template <int KS, int NT, int CHUNKS, bool PENDING, bool COPY, class PIPE, int NIN, int NX>
+__device__ __forceinline__ void dense_tm(PIPE& p, bf16x8 (&w0)[kGrp], bf16x8 (&w1)[kGrp], const bf16x8 (&Xin)[NIN], u32x4 (&Xa)[NX],
+                                         u32x4 (&Xb)[NX], f32x16 (&acc)[2], const float* bias_this, const float* bias_next, int hh) {
+    static_assert(NT % 2 == 0 && NX == 2 * NT && CHUNKS * kChunkFrags == NT * KS, "tile-major layer shape");
+    const unsigned nb_this = lds_base(bias_this, hh), nb_next = lds_base(bias_next, hh);
+    static_for<CHUNKS>([&](auto cc) {
+        consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) {
+            constexpr int g = decltype(cc)::value * kChunkFrags + decltype(ic)::value, nt = g / KS, ks = g % KS, b = nt & 1;
+            if constexpr (!COPY) acc[b] = MFMA(w, Xin[ks], acc[b]);
+            else if constexpr (ks < 2 * nt) acc[b] = MFMA(w, __builtin_bit_cast(bf16x8, Xa[ks]), acc[b]);
+            else acc[b] = MFMA(w, __builtin_bit_cast(bf16x8, Xb[ks]), acc[b]);
+            if constexpr (nt > 0 || PENDING) epi_at<KS, ks, (nt > 0 ? nt - 1 : NT - 1)>(acc[b ^ 1], Xb);
+            if constexpr (COPY && nt < NT - 1) {
+                if constexpr (ks == 12) Xa[2 * nt] = Xb[2 * nt];
+                if constexpr (ks == 14) Xa[2 * nt + 1] = Xb[2 * nt + 1];
+            }
+            constexpr int r0 = bias_first<KS>(ks), rn = bias_count<KS>(ks);
+            static_for<rn>([&](auto rc) {
+                if constexpr (nt < NT - 1) bias_piece<r0 + decltype(rc)::value>(acc[b ^ 1], nb_this, 32 * (nt + 1));
+                else bias_piece<r0 + decltype(rc)::value>(acc[b ^ 1], nb_next, 0);
+            });
+        });
+    });
+}
+
 // One 1-KiB LDS-DMA transfer outside the weight pipeline (next tile's records / time-embedding row): 64 lanes x 16 B
 // from `gp` (per lane) to LDS byte offset `dst` + lane * 16.  Counted by vmcnt in issue order like the weight pieces.
 __device__ __forceinline__ void dma16(const void* gp, unsigned dst) {
@@ -273,7 +350,6 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
     constexpr int KSH = H / 16;   // k-steps of a hidden activation
     constexpr int NTH = H / 32;   // tiles of a hidden layer
-    constexpr int HA = NTH - 4;   // first of the four accumulators the head uses (split-K)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // LDS after the chunk buffers: biases (+H zeros), the Tartan-Federer noise table, per-timestep (a, b),
@@ -292,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     }
 
-    Pipe<true> p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, 0};
+    Pipe<STAMP> p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, 0};
     p.fetch_all();  // chunk 0 -> buffer 0
     p.fetch_all();  // chunk 1 -> buffer 1
     p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
@@ -327,8 +403,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     bf16x8 w0[kGrp], w1[kGrp];
     static_for<kGrp>([&](auto ic) { w0[decltype(ic)::value] = p.ld(decltype(ic)::value); });
 
-    f32x16 acc[NTH];
-    bf16x8 X[KSH];
+    f32x16 acc[2];               // the two alternating accumulator tiles of the tile-major layers
+    f32x16 pacc[kDimT / 32];     // proj accumulators (emb[t] + proj bias, then D -> 128)
+    u32x4 Xa[KSH], Xb[KSH];     // activations as packed bf16 pairs, see dense_tm
     unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int slot) {
         PIN();  // phase boundary: keeps the scheduler from mixing the phases' register peaks (fewer spills)
@@ -410,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         asm volatile("" : "+v"(h4));
         const float* er = a.embb + (int64_t)t * a.emb_ld + h4;
         static_for<kDimT / 32>([&](auto ic) {
-            acc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value);
+            pacc[decltype(ic)::value] = load16(er + 32 * decltype(ic)::value);
             PIN();
         });
     };
@@ -452,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             });
             const unsigned eb = lds_base(semb, hh);
             static_for<kDimT / 32>([&](auto ic) {  // proj accumulators <- emb[t] + proj bias, from the staged row
-                acc[decltype(ic)::value] = load16_lds(eb, 32 * decltype(ic)::value);
+                pacc[decltype(ic)::value] = load16_lds(eb, 32 * decltype(ic)::value);
                 PIN();
             });
         }
@@ -461,37 +538,34 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         if constexpr (MODE == 0) t_nxt = request_t(nxt);
         const float* sb = sbias + kDimT;
         stamp(0);  // prologue
-        // ---- proj (D -> 128)
-        bf16x8 XP[kDimT / 16];  // proj output; not in X: the 128 -> H layer reads its last k-step while X is rewritten
-        dense<KS0, kDimT / 32, 1, false, NTH>(p, w0, w1, XI, XP, acc, sb, hh);
-        // ---- hidden layers (MODEL:300-301); activations are rewritten in place
-        sb += H;
+        // ---- proj (D -> 128): four tiles of 2 DT k-steps, k-step-major, its (short) epilogue exposed
+        bf16x8 XP[kDimT / 16];
+        dense<KS0, kDimT / 32, 1, false, 0>(p, w0, w1, XI, XP, pacc, sb, hh);
+        acc[0] = load16_lds(lds_base(sb, hh), 0);  // bias of the 128 -> H layer's tile 0; every later one rides in the stream
         stamp(1);  // proj
+        // ---- 128 -> H, then the H -> H layers (MODEL:300-301), tile-major (dense_tm)
         if (a.n_hidden == 1) stage(tile + gridDim.x);
-        dense<kDimT / 16, NTH, NTH*(kDimT / 16) / kChunkFrags, true, NTH>(p, w0, w1, XP, X, acc, sb, hh);
+        dense_tm<kDimT / 16, NTH, NTH*(kDimT / 16) / kChunkFrags, false, false>(p, w0, w1, XP, Xa, Xb, acc, sb, sb + H, hh);
         stamp(2);  // 128 -> H
         for (int l = 1; l < a.n_hidden; ++l) {
             sb += H;
             if (l == a.n_hidden - 1) stage(tile + gridDim.x);  // lands (and is fenced by the chunk barriers) before the head ends
-            dense<KSH, NTH, NTH * KSH / kChunkFrags, true, NTH>(p, w0, w1, X, X, acc, sb, hh);
+            dense_tm<KSH, NTH, NTH * KSH / kChunkFrags, true, true>(p, w0, w1, XP, Xa, Xb, acc, sb, sb + H, hh);
         }
+        sb += H;
         stamp(3);  // H -> H layers
-        // ---- head (H -> D), MODEL:303.  Only four accumulators are busy now: in MODE 0 the next tile's record and its
-        // ---- emb rows are requested here and land (in the free accumulators) while the head runs.
+        // ---- head (H -> D), MODEL:303: one accumulation chain per 32 output features; the last hidden tile's epilogue
+        // ---- (k-steps KSH-2, KSH-1 of the head's input) rides under the first steps of the head's first tile
         float sq = 0.0f;
         static_for<DT>([&](auto tc) {
-            constexpr int nt = decltype(tc)::value;
-            acc[HA] = load16_lds(lds_base(sb, hh), 32 * nt);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[HA + 1][r] = acc[HA + 2][r] = acc[HA + 3][r] = 0.0f;
-            // four independent accumulation chains over k (a single chain would wait out the MFMA latency)
+            constexpr int nt = decltype(tc)::value, hb = nt & 1;
+            if constexpr (nt > 0) acc[hb] = load16_lds(lds_base(sb, hh), 32 * nt);
             consume_chunk(p, w0, w1, [&](auto ic, const bf16x8& w) {
                 constexpr int ks = decltype(ic)::value;
-                acc[HA + (ks & 3)] = MFMA(w, X[ks], acc[HA + (ks & 3)]);
+                acc[hb] = MFMA(w, __builtin_bit_cast(bf16x8, Xb[ks]), acc[hb]);
+                if constexpr (nt == 0) epi_at<KSH, ks, NTH - 1>(acc[1], Xb);
             });
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = (acc[HA][r] + acc[HA + 1][r]) + (acc[HA + 2][r] + acc[HA + 3][r]);
+            const f32x16 o = acc[hb];
             if constexpr (MODE == 0) {
                 if (cur.valid) {
                     int64_t ocs = a.o_cs;  // opaque for the same reason as in request_x
@@ -713,10 +787,10 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
     // note: w32 is the zero-padded [out_pad][in_pad] image, so out_pad/in_pad are its true extents
     pack(c->proj, kDimT / 32, 2 * L.DT, 0, 1);
     boff += kDimT;
-    pack(c->blocks[0], nth, kDimT / 16, 0, nth * (kDimT / 16) / kChunkFrags);
+    pack(c->blocks[0], nth, kDimT / 16, 1, nth * (kDimT / 16) / kChunkFrags);
     boff += H;
     for (int i = 1; i < c->n_hidden; ++i) {
-        pack(c->blocks[i], nth, ksh, 0, nth * ksh / kChunkFrags);
+        pack(c->blocks[i], nth, ksh, 1, nth * ksh / kChunkFrags);
         boff += H;
     }
     pack(c->head, L.DT, ksh, 1, (L.DT * ksh + kChunkFrags - 1) / kChunkFrags);
