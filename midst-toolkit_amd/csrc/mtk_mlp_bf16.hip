@@ -62,7 +62,7 @@ struct FusedArgs {
     const SchedRow* sched;
     int add_t;
     unsigned long long* stamps;  // diagnostic: per-phase cycle sums (MTK_FUSED_STAMPS=1), else null
-    int exp;  // diagnostic switches (MTK_FUSED_EXP): 1 = no weight DMA after the prologue, 2 = no chunk barrier
+    int exp;  // diagnostic (MTK_FUSED_EXP with MTK_FUSED_STAMPS): which ablation build of the stamp kernel runs
     int t_list[kMaxTF];
 };
 
@@ -85,20 +85,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 // consumed, chunk c+1 has landed, chunk c+2 is in flight and chunk c+3 is being requested, one 1-KiB piece per
 // wave every fourth MFMA (an LDS-DMA costs the issuing wave tens of cycles, so the pieces are spread out rather
 // than issued as a burst that would drain the matrix pipe).
-template <bool DIAG>
+template <int EXP>  // EXP: compile-time ablation switches of the diagnostic (stamp) builds; 0 in the product kernels
 struct Pipe {
     const unsigned char* src;  // wfrag + lane * 16
     int total_chunks;
     int next;                  // chunk of the stream being requested
     unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer being filled
     int lane, wid;
-    int exp_;                  // diagnostic switches, honoured only by the DIAG (stamp) build
-    __device__ __forceinline__ int exp() const { return DIAG ? exp_ : 0; }
+    static constexpr int kExp = EXP;  // 1 = no weight DMA after the prologue, 2 = no chunk barrier, 4 = no layer epilogues
 
     // piece K (0..7) of the chunk being requested: fragment wid + 4 K; 64 lanes x 16 B, dest = base + lane * 16
     template <int K>
     __device__ __forceinline__ void piece() {
-        if (!(exp() & 1)) {
+        if constexpr (!(EXP & 1)) {
             const int f = wid + 4 * K;
             const unsigned dst = __builtin_amdgcn_readfirstlane(dma + (unsigned)f * kFragBytes);
             const unsigned char* gp = src + (size_t)next * kChunkBytes + (size_t)f * kFragBytes;
@@ -121,7 +120,7 @@ struct Pipe {
     // (chunk m+2) have landed, so chunk m+1 is complete; the barrier extends that to every wave and also says
     // every wave is done with chunk m-1, whose buffer the following pieces (chunk m+3) overwrite.
     __device__ __forceinline__ void sync() {
-        if (!(exp() & 2)) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if constexpr (!(EXP & 2)) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     }
     __device__ __forceinline__ void rotate() { rd = (rd + kChunkBytes == kBufs * kChunkBytes) ? 0u : rd + kChunkBytes; }
     __device__ __forceinline__ bf16x8 ld(int f) const {
@@ -233,12 +232,11 @@ __device__ __forceinline__ void dense(PIPE& p, bf16x8 (&w0)[kGrp], bf16x8 (&w1)[
             constexpr int g = decltype(cc)::value * kChunkFrags + decltype(ic)::value, ks = g / NT, nt = g % NT;
             if constexpr (ks < KS) acc[nt] = MFMA(w, Xin[ks], acc[nt]);
             if constexpr (ks == KS - 1) {  // last k-step: finish the tile issued two MFMAs ago
-                if (p.exp() & 4) return;
-                if constexpr (nt >= 2) finish(std::integral_constant<int, nt - 2>{});
+                if constexpr (!(PIPE::kExp & 4) && nt >= 2) finish(std::integral_constant<int, nt - 2>{});
             }
         });
     });
-    if (!(p.exp() & 4)) {
+    if constexpr (!(PIPE::kExp & 4)) {
         if constexpr (NT >= 2) finish(std::integral_constant<int, NT - 2>{});
         PIN();
         finish(std::integral_constant<int, NT - 1>{});
@@ -316,6 +314,7 @@ __device__ __forceinline__ void dense_tm(PIPE& p, bf16x8 (&w0)[kGrp], bf16x8 (&w
             if constexpr (!COPY) acc[b] = MFMA(w, Xin[ks], acc[b]);
             else if constexpr (ks < 2 * nt) acc[b] = MFMA(w, __builtin_bit_cast(bf16x8, Xa[ks]), acc[b]);
             else acc[b] = MFMA(w, __builtin_bit_cast(bf16x8, Xb[ks]), acc[b]);
+            if constexpr (PIPE::kExp & 4) return;  // diagnostic build only: no epilogue, no bias
             if constexpr (nt > 0 || PENDING) epi_at<KS, ks, (nt > 0 ? nt - 1 : NT - 1)>(acc[b ^ 1], Xb);
             if constexpr (COPY && nt < NT - 1) {
                 if constexpr (ks == 12) Xa[2 * nt] = Xb[2 * nt];
@@ -345,7 +344,7 @@ __device__ __forceinline__ void dma16(const void* gp, unsigned dst) {
 // MODE 1: Tartan-Federer score.  Tiles never straddle a timestep, so t is tile-uniform: the tile's records
 //         (a contiguous block of x, <= 128 x x_ld floats) and its emb[t] + bias row are brought into LDS by DMA during
 //         the previous tile's last hidden layer — no per-tile global load ever lands in a VGPR.
-template <int H, int DT, int MODE, bool STAMP = false>
+template <int H, int DT, int MODE, bool STAMP = false, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
     constexpr int KSH = H / 16;   // k-steps of a hidden activation
@@ -368,12 +367,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     }
 
-    Pipe<STAMP> p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid, 0};
+    Pipe<EXP> p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid};
     p.fetch_all();  // chunk 0 -> buffer 0
     p.fetch_all();  // chunk 1 -> buffer 1
     p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
     p.template piece<1>();
-    p.exp_ = a.exp;
 
     const int64_t n_tiles = (MODE == 1) ? a.tiles_per_k * a.nk : (a.rows + 127) / 128;
     // MODE 1: DMA of tile `tile`'s records and emb row into LDS (all waves take part)
@@ -406,6 +404,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     f32x16 acc[2];               // the two alternating accumulator tiles of the tile-major layers
     f32x16 pacc[kDimT / 32];     // proj accumulators (emb[t] + proj bias, then D -> 128)
     u32x4 Xa[KSH], Xb[KSH];     // activations as packed bf16 pairs, see dense_tm
+    if constexpr (EXP & 4) {  // ablation without epilogues: the activations are never written, give them defined (opaque) values
+#pragma unroll
+        for (int i = 0; i < KSH; ++i) asm volatile("" : "=v"(Xa[i]), "=v"(Xb[i]));
+    }
     unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int slot) {
         PIN();  // phase boundary: keeps the scheduler from mixing the phases' register peaks (fewer spills)
@@ -492,6 +494,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         });
     };
 
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (STAMP) {
+        clk0 = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     Where cur = locate(blockIdx.x);
     int t_cur = 0;
     if constexpr (MODE == 0) {
@@ -603,8 +610,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     }
     (void)t_cur;
     if constexpr (STAMP) {
+        st_sum[6] = __builtin_amdgcn_s_memtime() - clk0;      // shader cycles ...
+        st_sum[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // ... per 100 MHz tick: the clock held under this load
         if (lane == 0 && wid == 0)
-            for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_sum[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(a.stamps + i, st_sum[i]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches must land before the LDS is released
 }
@@ -706,19 +715,22 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     static const bool stamps_env = getenv("MTK_FUSED_STAMPS") != nullptr;
     if (stamps_env && L.DT == 1 && a.mode == 1) {
         static unsigned long long* d_st = nullptr;
+        using Kern = void (*)(FusedArgs);
+        static const Kern kerns[4] = {k_fused<512, 1, 1, true, 0>, k_fused<512, 1, 1, true, 1>, k_fused<512, 1, 1, true, 2>, k_fused<512, 1, 1, true, 4>};
+        const Kern kern = kerns[a.exp == 1 ? 1 : a.exp == 2 ? 2 : a.exp == 4 ? 3 : 0];
         if (!d_st) {
             MTK_HIP(hipMalloc(&d_st, 64));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fused<512, 1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+            for (Kern k : kerns) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         }
         MTK_HIP(hipMemsetAsync(d_st, 0, 64, s));
         a.stamps = d_st;
-        hipLaunchKernelGGL((k_fused<512, 1, 1, true>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
         MTK_HIP(hipStreamSynchronize(s));
         unsigned long long h[8];
         MTK_HIP(hipMemcpy(h, d_st, 64, hipMemcpyDeviceToHost));
         const double n = (double)h[5] > 0 ? (double)h[5] : 1.0;
-        fprintf(stderr, "[mtk stamps] tiles/wg-sum=%llu cycles/tile: prologue %.0f proj %.0f l1 %.0f hh %.0f head %.0f\n", h[5], h[0] / n, h[1] / n,
-                h[2] / n, h[3] / n, h[4] / n);
+        fprintf(stderr, "[mtk stamps] tiles/wg-sum=%llu cycles/tile: prologue %.0f proj %.0f l1 %.0f hh %.0f head %.0f; clock %.0f MHz\n", h[5], h[0] / n,
+                h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[7] ? 100.0 * (double)h[6] / (double)h[7] : 0.0);
         return MTK_OK;
     }
     return a.mode == 1 ? launch<512, 1>(L, a, grid, lds, s) : launch<512, 0>(L, a, grid, lds, s);
