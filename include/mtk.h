@@ -195,11 +195,21 @@ int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int first_step, con
 /* Replaces one iteration of sample_ddim's loop (GMD:1292-1308) after the denoiser call: gaussian_ddim_step (GMD:1070-1118)
  * and multinomial_ddim_step (GMD:1211-1257) with eta = 0, the only value sample_ddim passes (no noise term; the
  * categorical mixture keeps the x0 and the uniform branch).  Same state buffers as mtk_p_sample_step; the numeric state
- * stays fp32-representable (the reference's DDIM chain is fp32 throughout).  u: [B, S] row-major or NULL -> Philox.
- * Score-based guidance (condition_score, GMD:617-661) is not implemented. */
+ * stays fp32-representable (the reference's DDIM chain is fp32 throughout).  u: [B, S] row-major or NULL -> Philox. */
 int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
                   int32_t* z_idx, const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0,
                   mtk_stream stream);
+/* The same step for any eta >= 0 and with score-based guidance: gaussian_ddim_step's sigma / noise term (GMD:1109-1116;
+ * noise [B, Nn] row-major fp32 as torch.randn_like(features) returned it, or NULL -> Philox), multinomial_ddim_step's
+ * "stay" branch coef1 = sigma (GMD:1241-1256), and condition_score (GMD:617-661, called at GMD:1104-1105): grad [B, Nn]
+ * row-major fp32 = conditioning_function(features, timestep) for the CURRENT state, or NULL. */
+int mtk_ddim_step_ex(mtk_ctx* ctx, int64_t B, int t, double eta, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
+                     int32_t* z_idx, const float* noise, const float* u, const float* grad, float* x_in_next, int64_t xi_rs,
+                     int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream);
+/* Replaces one iteration of gaussian_ddim_reverse_sample's loop (GMD:1209-1213) after the denoiser call:
+ * gaussian_ddim_reverse_step (GMD:1160-1186), numeric features only, on the same fp64 state buffer z [Nn][B]. */
+int mtk_ddim_reverse_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
+                          float* x_in_next, int64_t xi_rs, int64_t xi_cs, mtk_stream stream);
 
 /* Replaces the initial draw of sample() (GMD:1392-1399): z0 [B, Nn] row-major fp32 (or NULL → Philox)
  * into the fp64 state z [Nn][B]; categories by Gumbel-argmax of uniform logits from u0 [B, S]

@@ -47,6 +47,8 @@ _SIGS = {
     "mtk_affine_inverse": (C.c_int, [_i32, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "mtk_quantile_inverse": (C.c_int, [_i32, _i64, _i32, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "mtk_ddim_step": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),
+    "mtk_ddim_step_ex": (C.c_int, [_p, _i64, _i32, C.c_double, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),
+    "mtk_ddim_reverse_step": (C.c_int, [_p, _i64, _i32, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "mtk_p_sample_step_guided": (C.c_int, [_p, _i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),
     "mtk_sample_init": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _u64, _u64, _p]),
     "mtk_sample_decode": (C.c_int, [_p, _i64, _p, _p, _p, _p]),

@@ -369,19 +369,25 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
     }
 }
 
-// One DDIM step with eta = 0, the only value sample_ddim (GMD:1259-1316) ever passes: gaussian_ddim_step (GMD:1070-1118)
-// and multinomial_ddim_step (GMD:1211-1257).  Everything stays fp32 in the reference (no fp64 table is involved), so the
-// state — kept in the fp64 buffer of the ancestral chain — holds fp32-representable values and all arithmetic is fp32 in
-// the reference's operation order.  sigma = 0: the noise term vanishes, coef1 = 0 puts -inf on the "stay" branch of the
-// categorical mixture, which leaves logsumexp(log(abp) + log_x0, log(1 - abp) - log K).
+// One DDIM step: gaussian_ddim_step (GMD:1070-1118, with the score-based guidance of condition_score, GMD:617-661, when the
+// caller hands the conditioning function's gradient) and multinomial_ddim_step (GMD:1211-1257), for any eta.  Everything
+// stays fp32 in the reference (no fp64 table is involved), so the state — kept in the fp64 buffer of the ancestral chain
+// — holds fp32-representable values and all arithmetic is fp32 in the reference's operation order.  With eta = 0 (all
+// sample_ddim passes) sigma = 0: the noise term vanishes and coef1 = 0 puts -inf on the "stay" branch of the categorical
+// mixture, which leaves logsumexp(log(abp) + log_x0, log(1 - abp) - log K).
 struct DdimArgs {
     DevTables d;
     int64_t B;
     int t;
-    float sqrt_recip, sqrt_recipm1, c_x0, c_eps, log_c2, log_c3;  // c_x0 = sqrt(abp), c_eps = sqrt(1 - abp); logs of coef2 / coef3
+    float sqrt_recip, sqrt_recipm1, c_x0, c_eps;  // c_x0 = sqrt(abp), c_eps = sqrt(1 - abp - sigma^2)
+    float sig_mask;                               // (t != 0) * sigma: factor of the Gaussian noise (GMD:1115-1116)
+    float sqrt_1m_ab;                             // sqrt(1 - alpha_bar): factor of the guidance gradient (GMD:652)
+    float log_c1, log_c2, log_c3;                 // logs of the mixture coefficients (GMD:1243-1245)
     const float* mo; int64_t mo_rs, mo_cs;
     double* z;
     int32_t* z_idx;
+    const float* noise;  // [B, Nn] row-major fp32, NULL -> Philox (only read when sig_mask != 0)
+    const float* grad;   // [B, Nn] row-major fp32 or NULL
     const float* u;
     float* x_in; int64_t xi_rs, xi_cs;
     uint64_t seed, row0;
@@ -393,17 +399,24 @@ __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
     // seed / first global row: kernel arguments, or - for launches replayed from a HIP graph - a device pair (mtk_ctx_set_seed_source)
     const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
-    const uint32_t stream_u = MTK_STREAM_STEP + 2u * (uint32_t)a.t + 1u;
+    const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)a.t, stream_u = stream_n + 1u;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
         const float* mo = a.mo + row * a.mo_rs;
         float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
         PhiloxU pu(seed_, row0_ + row, stream_u);
+        PhiloxN pn(seed_, row0_ + row, stream_n);
         for (int j = 0; j < Nn; ++j) {
             double* zp = a.z + (int64_t)j * a.B + row;
             const float zf = (float)*zp, eh = mo[j * a.mo_cs];
-            const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;       // GMD:545 _predict_features_start_from_eps
+            float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;             // GMD:545 _predict_features_start_from_eps
+            if (a.grad) {                                                    // condition_score, GMD:649-655
+                float e = (a.sqrt_recip * zf - x0h) / a.sqrt_recipm1;
+                e = e - a.sqrt_1m_ab * a.grad[row * Nn + j];
+                x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * e;
+            }
             const float eps = (a.sqrt_recip * zf - x0h) / a.sqrt_recipm1;    // GMD:580-583
-            const float zn = x0h * a.c_x0 + a.c_eps * eps;                   // GMD:1114, sigma = 0
+            float zn = x0h * a.c_x0 + a.c_eps * eps;                         // GMD:1114
+            if (a.sig_mask != 0.0f) zn = zn + a.sig_mask * (a.noise ? a.noise[row * Nn + j] : pn.normal(j));  // GMD:1116
             *zp = (double)zn;
             if (xo) xo[j * a.xi_cs] = zn;
         }
@@ -411,6 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
             const float cc = a.log_c3 - s.logK[k];
             const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+            const int cur = a.z_idx[(int64_t)k * a.B + row];
             float mx = -INFINITY;
             for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.mo_cs]);
             float sum = 0.0f;
@@ -419,9 +433,11 @@ __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
             float best = -INFINITY;
             int arg = 0;
             for (int i = 0; i < Kk; ++i) {
-                const float b = a.log_c2 + ((mc[i * a.mo_cs] - mx) - lsum);  // log(coef2) + log_softmax (GMD:761)
-                const float m = fmaxf(b, cc);
-                const float logp = (m == -INFINITY) ? m : m + logf(expf(b - m) + expf(cc - m));  // torch.logsumexp over (-inf, b, cc)
+                const float st = a.log_c1 + ((i == cur) ? 0.0f : MTK_LOG_TINY);  // log(coef1) + log one-hot of the state
+                const float b = a.log_c2 + ((mc[i * a.mo_cs] - mx) - lsum);      // log(coef2) + log_softmax (GMD:761)
+                const float m = fmaxf(fmaxf(st, b), cc);
+                // torch.logsumexp over (stay, x0, uniform): exp(-inf - m) = 0 drops the stay branch when eta = 0
+                const float logp = (m == -INFINITY) ? m : m + logf((expf(st - m) + expf(b - m)) + expf(cc - m));
                 const float g = a.u ? gumbel(a.u[row * S + o + i]) : gumbel_fast(pu.uniform(o + i));
                 const float v = g + logp;
                 if (v > best || i == 0) { best = v; arg = i; }
@@ -429,6 +445,30 @@ __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
             a.z_idx[(int64_t)k * a.B + row] = arg;
             if (xo)
                 for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+        }
+    }
+}
+
+// gaussian_ddim_reverse_step (GMD:1160-1186): the deterministic DDIM map run towards noise, numeric features only, fp32.
+struct DdimRevArgs {
+    int64_t B;
+    int Nn;
+    float sqrt_recip, sqrt_recipm1, c_x0, c_eps;  // sqrt(alpha_bar_next), sqrt(1 - alpha_bar_next)
+    const float* mo; int64_t mo_rs, mo_cs;
+    double* z;
+    float* x_in; int64_t xi_rs, xi_cs;
+};
+
+__global__ __launch_bounds__(kBlock) void k_ddim_reverse_step(DdimRevArgs a) {
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
+        for (int j = 0; j < a.Nn; ++j) {
+            double* zp = a.z + (int64_t)j * a.B + row;
+            const float zf = (float)*zp, eh = a.mo[row * a.mo_rs + j * a.mo_cs];
+            const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;     // GMD:1177 -> 545
+            const float eps = (a.sqrt_recip * zf - x0h) / a.sqrt_recipm1;  // GMD:1179-1182
+            const float zn = x0h * a.c_x0 + a.c_eps * eps;                 // GMD:1186
+            *zp = (double)zn;
+            if (a.x_in) a.x_in[row * a.xi_rs + j * a.xi_cs] = zn;
         }
     }
 }
@@ -1380,12 +1420,13 @@ extern "C" int mtk_p_sample_step(mtk_ctx* ctx, int64_t B, int t, int first_step,
                                     x_in_next, xi_rs, xi_cs, seed, row0, stream);
 }
 
-extern "C" int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
-                             int32_t* z_idx, const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed,
-                             uint64_t row0, mtk_stream stream) {
+extern "C" int mtk_ddim_step_ex(mtk_ctx* ctx, int64_t B, int t, double eta, const float* model_out, int64_t mo_rs, int64_t mo_cs,
+                                double* z, int32_t* z_idx, const float* noise, const float* u, const float* grad, float* x_in_next,
+                                int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: null context");
     if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: t = %d outside [0, %d)", t, ctx->T);
     if (B < 0 || !model_out || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: null pointer or negative B");
+    if (!(eta >= 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: eta = %g must be >= 0", eta);
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
     DdimArgs a;
@@ -1393,16 +1434,48 @@ extern "C" int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_
     a.B = B; a.t = t;
     a.sqrt_recip = (float)ctx->tab(MTK_TAB_SQRT_RECIP_ACP, t);
     a.sqrt_recipm1 = (float)ctx->tab(MTK_TAB_SQRT_RECIPM1_ACP, t);
-    const float abp = (float)ctx->tab(MTK_TAB_ACP_PREV, t);
-    const float coef3 = (1.0f - 0.0f) - abp;  // 1 - coef1 - coef2 with sigma = 0 (GMD:1243-1245)
+    // GMD:1109-1111 / 1239-1245 in fp32 torch ops (this file is built without fma contraction, host side included)
+    const float ab = (float)ctx->tab(MTK_TAB_ACP, t), abp = (float)ctx->tab(MTK_TAB_ACP_PREV, t);
+    const float sigma = ((float)eta * sqrtf((1.0f - abp) / (1.0f - ab))) * sqrtf(1.0f - ab / abp);
+    const float coef1 = sigma, coef2 = abp - sigma * ab, coef3 = (1.0f - coef1) - coef2;
     a.c_x0 = sqrtf(abp);
-    a.c_eps = sqrtf((1.0f - abp) - 0.0f);
-    a.log_c2 = logf(abp);
-    a.log_c3 = coef3 > 0.0f ? logf(coef3) : -INFINITY;
+    a.c_eps = sqrtf((1.0f - abp) - sigma * sigma);
+    a.sig_mask = (t != 0 ? 1.0f : 0.0f) * sigma;
+    a.sqrt_1m_ab = sqrtf(1.0f - ab);
+    a.log_c1 = coef1 > 0.0f ? logf(coef1) : -INFINITY;
+    a.log_c2 = logf(coef2);
+    a.log_c3 = coef3 > 0.0f ? logf(coef3) : (coef3 == 0.0f ? -INFINITY : NAN);
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
-    a.z = z; a.z_idx = z_idx; a.u = u;
+    a.z = z; a.z_idx = z_idx; a.noise = noise; a.grad = grad; a.u = u;
     a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0; a.seed_src = ctx->seed_src;
     hipLaunchKernelGGL(k_ddim_step, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false), (hipStream_t)stream, a);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+extern "C" int mtk_ddim_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
+                             int32_t* z_idx, const float* u, float* x_in_next, int64_t xi_rs, int64_t xi_cs, uint64_t seed,
+                             uint64_t row0, mtk_stream stream) {
+    return mtk_ddim_step_ex(ctx, B, t, 0.0, model_out, mo_rs, mo_cs, z, z_idx, nullptr, u, nullptr, x_in_next, xi_rs, xi_cs, seed, row0, stream);
+}
+
+extern "C" int mtk_ddim_reverse_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out, int64_t mo_rs, int64_t mo_cs, double* z,
+                                     float* x_in_next, int64_t xi_rs, int64_t xi_cs, mtk_stream stream) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_reverse_step: null context");
+    if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_reverse_step: t = %d outside [0, %d)", t, ctx->T);
+    if (B < 0 || !model_out || (ctx->Nn > 0 && !z)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_reverse_step: null pointer or negative B");
+    if (B == 0 || ctx->Nn == 0) return MTK_OK;
+    MTK_HIP(hipSetDevice(ctx->device));
+    DdimRevArgs a;
+    a.B = B; a.Nn = ctx->Nn;
+    a.sqrt_recip = (float)ctx->tab(MTK_TAB_SQRT_RECIP_ACP, t);
+    a.sqrt_recipm1 = (float)ctx->tab(MTK_TAB_SQRT_RECIPM1_ACP, t);
+    const float abn = t + 1 < ctx->T ? (float)ctx->tab(MTK_TAB_ACP, t + 1) : 0.0f;  // alphas_cumprod_next, GMD:262
+    a.c_x0 = sqrtf(abn);
+    a.c_eps = sqrtf(1.0f - abn);
+    a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
+    a.z = z; a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs;
+    hipLaunchKernelGGL(k_ddim_reverse_step, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }

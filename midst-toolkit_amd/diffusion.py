@@ -418,9 +418,15 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             elif not philox:
                 if Nn and not ddim:
                     n = torch.randn((B, Nn), device=dev, dtype=torch.float32 if i == 0 else torch.float64)
+                elif Nn:
+                    torch.randn((B, Nn), device=dev)  # GMD:1113 draws (and, eta = 0, discards) it: keep the generator in step
                 u = draw_u() if C else None
             if ddim:  # GMD:1292-1308, eta = 0: no Gaussian noise enters (the reference draws it and multiplies by sigma = 0)
-                eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed, row0)
+                if conditioning_function is not None and Nn:  # condition_score (GMD:1104-1105): the state is fp32 here
+                    tvec = torch.full((B,), t, device=dev, dtype=torch.long)
+                    grad = conditioning_function(z[:Nn].t().float().contiguous(), tvec, **model_kwargs)
+                    grad = grad.detach().to(device=dev, dtype=torch.float32).contiguous()
+                eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed, row0, grad=grad)
                 continue
             if conditioning_function is not None and Nn:
                 feats = z[:Nn].t().contiguous()
@@ -503,11 +509,57 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
     @torch.no_grad()
     def sample_ddim(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
                     conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None) -> tuple[Tensor, dict[str, Tensor]]:
-        """GMD:1259 (eta = 0).  Returns ([B, Nn + C] fp32 on CPU, {"y": labels})."""
-        if conditioning_function is not None:
-            raise NotImplementedError("score-based guidance of the DDIM chain (condition_score, GMD:617-661) is not on the MI355X path")
-        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected), model_kwargs, None, _injected, ddim=True,
-                                   row0=row0, seed=seed)
+        """GMD:1259 (eta = 0).  Returns ([B, Nn + C] fp32 on CPU, {"y": labels}).  ``conditioning_function``: score-based
+        guidance of the numeric features (condition_score, GMD:617-661)."""
+        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected), model_kwargs, conditioning_function,
+                                   _injected, ddim=True, row0=row0, seed=seed)
+
+    @torch.no_grad()
+    def gaussian_ddim_sample(self, noise: Tensor, num_timesteps: int, outputs: dict[str, Tensor], eta: float = 0.0,
+                             model_kwargs: Any | None = None, conditioning_function=None, _injected: list | None = None) -> Tensor:
+        """GMD:1119: the Gaussian DDIM chain from ``noise`` [B, D] over ``reversed(range(num_timesteps))`` for any eta, with
+        optional score-based guidance.  The denoiser sees the whole feature vector, as in the reference; the table must be
+        numeric-only (the reference feeds ``features`` straight to the denoiser, so any categorical block would have to be
+        part of them).  ``_injected``: the per-step ``randn_like`` draws (tests).  Returns fp32 [B, D] on the state's device."""
+        return self._gaussian_ddim_loop(noise, list(reversed(range(num_timesteps))), eta, model_kwargs, conditioning_function, _injected, False)
+
+    @torch.no_grad()
+    def gaussian_ddim_reverse_sample(self, features: Tensor, num_timesteps: int, outputs: dict[str, Tensor]) -> Tensor:
+        """GMD:1189: the deterministic DDIM map run from data towards noise, ``range(num_timesteps)``."""
+        return self._gaussian_ddim_loop(features, list(range(num_timesteps)), 0.0, None, None, None, True)
+
+    def _gaussian_ddim_loop(self, start: Tensor, steps: list, eta: float, model_kwargs, conditioning_function, inj, reverse: bool) -> Tensor:
+        if self._has_cat:
+            raise ValueError("gaussian_ddim_sample / gaussian_ddim_reverse_sample: numeric-only tables (num_classes = [0])")
+        eng = self.engine()
+        dev = eng.device
+        Nn, D = eng.Nn, eng.D
+        B = int(start.shape[0])
+        if tuple(start.shape) != (B, D):
+            raise ValueError(f"expected [B, {D}] features, got {tuple(start.shape)}")
+        philox = self.rng == "philox" and inj is None
+        seed = int(torch.randint(1, 2**62, (1,)).item()) if philox else 0
+        model_kwargs = model_kwargs or {}
+        z = start.to(device=dev, dtype=torch.float64).t().contiguous()
+        z_idx = torch.empty((1, B), dtype=torch.int32, device=dev)
+        x_in = start.to(device=dev, dtype=torch.float32).t().contiguous()
+        out = torch.empty((D, B), dtype=torch.float32, device=dev)
+        for i, t in enumerate(steps):
+            self._denoise_cm(eng, x_in, t, B, out)
+            if reverse:
+                eng.ddim_reverse_step(B, t, out, (1, B), z, x_in, (1, B))
+                continue
+            n = grad = None
+            if inj is not None:
+                n = inj[i].to(device=dev, dtype=torch.float32).contiguous()
+            elif not philox:
+                n = torch.randn((B, Nn), device=dev)  # GMD:1113, drawn at every step whatever eta is
+            if conditioning_function is not None:
+                tvec = torch.full((B,), t, device=dev, dtype=torch.long)
+                grad = conditioning_function(z.t().float().contiguous(), tvec, **model_kwargs)
+                grad = grad.detach().to(device=dev, dtype=torch.float32).contiguous()
+            eng.ddim_step(B, t, out, (1, B), z, z_idx, None, x_in, (1, B), seed, 0, eta=eta, noise=n, grad=grad)
+        return z.t().float().contiguous()
 
     def conditional_sample(self, targets: Tensor, model_kwargs: dict[str, Any] | None = None, conditioning_function=None,
                            _injected: dict | None = None) -> tuple[Tensor, dict[str, Tensor]]:

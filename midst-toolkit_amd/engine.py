@@ -185,10 +185,22 @@ class Engine:
                                                       ptr(z_idx), ptr(noise), nf64, ptr(u), ptr(grad), ptr(x_in_next), xi_strides[0],
                                                       xi_strides[1], seed, row0, self._stream()))
 
-    def ddim_step(self, B, t, model_out, mo_strides, z, z_idx, u, x_in_next, xi_strides, seed=0, row0=0):
+    def ddim_step(self, B, t, model_out, mo_strides, z, z_idx, u, x_in_next, xi_strides, seed=0, row0=0, eta=0.0, noise=None, grad=None):
+        """gaussian_ddim_step + multinomial_ddim_step (GMD:1070-1118, 1211-1257).  ``noise``: [B, Nn] fp32 (``randn_like``) or None ->
+        Philox, only read when eta > 0; ``grad``: [B, Nn] fp32 conditioning gradient of condition_score (GMD:617-661) or None."""
+        for name, v in (("noise", noise), ("guidance gradient", grad)):
+            if v is not None and (v.dtype != torch.float32 or not v.is_contiguous() or tuple(v.shape) != (B, self.Nn)):
+                raise ValueError(f"{name} must be a contiguous fp32 [{B}, {self.Nn}] tensor, got {tuple(v.shape)} {v.dtype}")
         with torch.cuda.device(self.device):
-            check(_lib.lib().mtk_ddim_step(self._h, B, int(t), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z), ptr(z_idx), ptr(u),
-                                           ptr(x_in_next), xi_strides[0], xi_strides[1], seed, row0, self._stream()))
+            check(_lib.lib().mtk_ddim_step_ex(self._h, B, int(t), float(eta), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z), ptr(z_idx),
+                                              ptr(noise), ptr(u), ptr(grad), ptr(x_in_next), xi_strides[0], xi_strides[1], seed, row0,
+                                              self._stream()))
+
+    def ddim_reverse_step(self, B, t, model_out, mo_strides, z, x_in_next, xi_strides):
+        """gaussian_ddim_reverse_step (GMD:1160-1186) on the numeric state."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_ddim_reverse_step(self._h, B, int(t), ptr(model_out), mo_strides[0], mo_strides[1], ptr(z), ptr(x_in_next),
+                                                   xi_strides[0], xi_strides[1], self._stream()))
 
     def sample_decode(self, B, z, z_idx, out):
         with torch.cuda.device(self.device):

@@ -424,17 +424,33 @@ def classifier_conditioning_function(state: dict[str, torch.Tensor], scale: floa
 
 
 # --------------------------------------------------------------------------- DDIM (section 8f rank 4)
-def gaussian_ddim_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor, eta: float = 0.0):
-    """GMD:1070-1118 (no conditioning): every table involved is fp32, so an fp32 state stays fp32."""
+def gaussian_ddim_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor, eta: float = 0.0,
+                       cond_grad: torch.Tensor | None = None):
+    """GMD:1070-1118: every table involved is fp32, so an fp32 state stays fp32.  ``cond_grad`` = what the conditioning
+    function returned for (z, t): condition_score (GMD:617-661) then replaces the predicted x0."""
     tt = torch.full((z.shape[0],), t, dtype=torch.long)
     col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731
     x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat  # GMD:545
-    eps = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)    # GMD:580-583
     ab, abp = col(s.alphas_cumprod), col(s.alphas_cumprod_prev)
+    if cond_grad is not None:
+        e = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)  # GMD:651
+        e = e - (1 - ab).sqrt() * cond_grad                                                       # GMD:652
+        x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * e    # GMD:655
+    eps = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)    # GMD:580-583
     sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
     mean_pred = x0_hat * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma**2) * eps
     mask = (tt != 0).float().view(-1, 1)
     return mean_pred + mask * sigma * noise
+
+
+def gaussian_ddim_reverse_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int):
+    """GMD:1160-1186."""
+    tt = torch.full((z.shape[0],), t, dtype=torch.long)
+    col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731
+    x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat
+    eps = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)
+    abn = col(s.alphas_cumprod_next)
+    return x0_hat * torch.sqrt(abn) + torch.sqrt(1 - abn) * eps
 
 
 def multinomial_ddim_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tensor, t: int, u: torch.Tensor, eta: float = 0.0):

@@ -73,6 +73,20 @@ def load_ddim(tag: str) -> dict:
     return d
 
 
+def load_ddimx(tag: str = "A_numeric") -> dict:
+    """Fixture of tools/make_golden.py::gen_ddim_family: gaussian_ddim_sample (eta > 0, with and without condition_score),
+    sample_ddim with a conditioning function, gaussian_ddim_reverse_sample and multinomial_ddim_step (eta > 0) of the reference."""
+    with np.load(os.path.join(GOLDEN, f"ddimx_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    d["Nn"], d["T"], d["md_T"] = int(d["Nn"]), int(d["T"]), int(d["md_T"])
+    for k in ("scale", "eta", "eta_cs", "md_eta"):
+        d[k] = float(d[k])
+    d["d_layers"] = [int(v) for v in d["d_layers"]]
+    d["K"], d["C"], d["S"], d["D"], d["sched"] = np.asarray([0], dtype=np.int64), 0, 0, d["Nn"], "cosine"
+    d["md_K"] = d["md_K"].astype(np.int64)
+    return d
+
+
 def load_classifier(tag: str = "A_numeric") -> dict:
     """Fixture of tools/make_golden.py::gen_classifier: the reference's own Classifier (eval mode) and conditioning function."""
     with np.load(os.path.join(GOLDEN, f"classifier_{tag}.npz")) as z:

@@ -389,6 +389,53 @@ def test_ddim_chain(tag):
         assert bool((codes == codes.round()).all()) and bool((codes >= 0).all()) and bool((codes < torch.tensor(c["K"]).float()).all())
 
 
+def test_ddim_family():
+    """f4: the rest of the DDIM family against the reference's outputs (tests/golden/ddimx_A_numeric.npz): gaussian_ddim_sample with
+    eta > 0 (GMD:1119) without and with score-based guidance (condition_score, GMD:617-661), sample_ddim with a conditioning
+    function, gaussian_ddim_reverse_sample (GMD:1189), and one multinomial_ddim_step with eta > 0 (GMD:1218) through the C ABI."""
+    from tests.helpers import guidance_function, load_ddimx
+
+    c = load_ddimx()
+    Nn, T, B = c["Nn"], c["T"], c["z0"].shape[0]
+    d = build(c, T=T)
+    cond = guidance_function(tt(c["centers"]), c["scale"], T)
+    y = tt(c["targets"]).to(dev())
+    z0 = tt(c["z0"]).to(dev())
+    got = d.gaussian_ddim_sample(z0, T, {}, eta=c["eta"], _injected=[tt(n) for n in c["eta_noise"]])
+    assert got.dtype == torch.float32
+    close(got, tt(c["eta_sample"]), rtol=RTOL, atol=1e-5)
+    got = d.gaussian_ddim_sample(z0, T, {}, eta=c["eta_cs"], model_kwargs={"y": y}, conditioning_function=cond, _injected=[tt(n) for n in c["etacs_noise"]])
+    close(got, tt(c["etacs_sample"]), rtol=RTOL, atol=1e-5)
+    assert float((got.cpu() - tt(c["eta_sample"])).abs().max()) > 1e-2
+    inj = {"z0": tt(c["sd_z0"]).to(dev()), "noise": [None] * T, "y": tt(c["sd_y"])}
+    got, outs = d.sample_ddim(B, torch.ones(3), model_kwargs={"y": y}, conditioning_function=cond, _injected=inj)
+    close(got, tt(c["sd_sample"]), rtol=RTOL, atol=1e-5)
+    got = d.gaussian_ddim_reverse_sample(tt(c["x_data"]).to(dev()), T, {})
+    close(got, tt(c["rev_sample"]), rtol=RTOL, atol=1e-5)
+    # philox mode runs, and eta > 0 adds noise
+    d.rng = "philox"
+    a = d.gaussian_ddim_sample(z0, T, {}, eta=0.0)
+    b = d.gaussian_ddim_sample(z0, T, {}, eta=0.0)
+    e = d.gaussian_ddim_sample(z0, T, {}, eta=0.7)
+    assert torch.equal(a, b) and float((a - e).abs().max()) > 1e-3 and not bool(e.isnan().any())
+    # multinomial_ddim_step, eta > 0: the categorical draw of one step, straight through the engine
+    import midst_toolkit_amd as mtk
+
+    K = c["md_K"]
+    net = mtk.MLPDiffusion(int(K.sum()) + 1, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([32], 0.0))
+    dc = mtk.GaussianMultinomialDiffusion(K, 1, net, num_timesteps=c["md_T"], device=dev()).to(dev())
+    eng = dc.engine()
+    Bc, S, Cc = c["md_out_cat"].shape[0], int(K.sum()), len(K)
+    mo = torch.cat([torch.zeros((Bc, 1)), tt(c["md_out_cat"])], 1).to(dev()).contiguous()
+    for t in (0, 1, 7, 15):
+        z = torch.zeros((1, Bc), dtype=torch.float64, device=dev())
+        z_idx = tt(c["md_z_idx"]).t().contiguous().to(device=dev(), dtype=torch.int32)
+        eng.ddim_step(Bc, t, mo, (S + 1, 1), z, z_idx, tt(c[f"md_u_{t}"]).to(dev()).contiguous(), None, (0, 0), eta=c["md_eta"],
+                      noise=torch.zeros((Bc, 1), device=dev()))
+        want = tt(c[f"md_idx_{t}"]).t().to(torch.int32)
+        assert torch.equal(z_idx.cpu(), want), (t, int((z_idx.cpu() != want).sum()))
+
+
 def test_conditional_sample_rejects_categorical_tables():
     c = load_case("B_ragged")
     d = build(c, T=4)

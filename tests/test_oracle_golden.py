@@ -202,3 +202,39 @@ def test_classifier_restatement_matches_the_reference_classifier():
     got = orc.sample_chain(s, np.array([0]), c["Nn"], c["params"], tt(c["cs_z0"]), None, noise, [None] * c["T"], conditioning_function=cond,
                            model_kwargs={"y": targets})
     torch.testing.assert_close(got, tt(c["cs_sample"]), rtol=1e-6, atol=1e-6)
+
+
+def test_ddim_family_bit_exact():
+    """The rest of the DDIM family (tests/golden/ddimx_A_numeric.npz, generated from the reference): gaussian_ddim_sample with
+    eta > 0 (GMD:1119), with condition_score (GMD:617-661), sample_ddim with a conditioning function (GMD:1259),
+    gaussian_ddim_reverse_sample (GMD:1189) and multinomial_ddim_step with eta > 0 (GMD:1218): the oracle's restatements give
+    the reference's outputs bit for bit."""
+    from tests.helpers import guidance_function, load_ddimx
+
+    c = load_ddimx()
+    Nn, T, B = c["Nn"], c["T"], c["z0"].shape[0]
+    s = orc.make_schedule(T, "cosine")
+    params = case_params(c)
+    cond = guidance_function(tt(c["centers"]), c["scale"], T)
+    y = tt(c["targets"])
+
+    def chain(z, noises, eta, guided, y_):
+        for i, t in enumerate(reversed(range(T))):
+            tv = torch.full((B,), t, dtype=torch.long)
+            out = orc.mlp_forward(params, z.float(), tv).float()
+            g = cond(z, tv, y=y_) if guided else None
+            z = orc.gaussian_ddim_step(s, out, z, t, noises[i], eta=eta, cond_grad=g)
+        return z
+
+    assert torch.equal(chain(tt(c["z0"]), [tt(n) for n in c["eta_noise"]], c["eta"], False, y), tt(c["eta_sample"]))
+    assert torch.equal(chain(tt(c["z0"]), [tt(n) for n in c["etacs_noise"]], c["eta_cs"], True, y), tt(c["etacs_sample"]))
+    zeros = [torch.zeros((B, Nn))] * T
+    assert torch.equal(chain(tt(c["sd_z0"]), zeros, 0.0, True, y), tt(c["sd_sample"]))
+    z = tt(c["x_data"])
+    for t in range(T):
+        z = orc.gaussian_ddim_reverse_step(s, orc.mlp_forward(params, z.float(), torch.full((B,), t, dtype=torch.long)).float(), z, t)
+    assert torch.equal(z, tt(c["rev_sample"]))
+    sm = orc.make_schedule(c["md_T"], "cosine")
+    for t in (0, 1, 7, 15):
+        got = orc.multinomial_ddim_step(sm, c["md_K"], tt(c["md_out_cat"]), tt(c["md_z_idx"]), t, tt(c[f"md_u_{t}"]), eta=c["md_eta"])
+        assert torch.equal(got, tt(c[f"md_idx_{t}"])), t

@@ -487,6 +487,63 @@ def gen_ddim(tag, K, Nn, d_layers, T_chain, B, sched="cosine"):
     print(f"ddim {tag}: B={B} dtype={smp.dtype}")
 
 
+def gen_ddim_family(tag="A_numeric", Nn=8, d_layers=(64, 64), T_chain=12, B=48, n_classes=3, scale=0.35):
+    """The rest of the reference's DDIM family, every draw captured: gaussian_ddim_sample with eta > 0 (GMD:1119), the same with
+    score-based guidance (condition_score, GMD:617-661), sample_ddim with a conditioning function (GMD:1259, eta = 0),
+    gaussian_ddim_reverse_sample (GMD:1189), and multinomial_ddim_step with eta > 0 (GMD:1218) on a ragged categorical table."""
+    diff, params = build([0], Nn, list(d_layers), T_chain)
+    g = torch.Generator().manual_seed(4100)
+    centers = torch.randn((n_classes, Nn), generator=g)
+    targets = torch.randint(0, n_classes, (B, 1), generator=g)
+    cond = guidance_function(centers, scale, T_chain)
+    z0 = torch.randn((B, Nn), generator=g)
+    x_data = torch.randn((B, Nn), generator=g) * 0.8
+    out = {"Nn": np.array(Nn), "d_layers": np.array(d_layers), "T": np.array(T_chain), "centers": centers.numpy(), "scale": np.array(scale),
+           "targets": targets.numpy(), "z0": z0.numpy(), "x_data": x_data.numpy(), "eta": np.array(0.6), "eta_cs": np.array(0.4)}
+    out.update({f"w_{k}": v.numpy() for k, v in params.items()})
+    for name, kw in (("eta", dict(eta=0.6)), ("etacs", dict(eta=0.4, model_kwargs={"y": targets}, conditioning_function=cond))):
+        log: list = []
+        torch.manual_seed(31 if name == "eta" else 32)
+        with capture_rng(log):
+            smp = diff.gaussian_ddim_sample(z0.clone(), T_chain, {}, **kw)
+        assert [e[0] for e in log] == ["randn_like"] * T_chain
+        out[f"{name}_noise"] = np.stack([e[1].numpy() for e in log])
+        out[f"{name}_sample"] = smp.numpy()
+        assert smp.dtype == torch.float32
+    log = []
+    torch.manual_seed(33)
+    with capture_rng(log):
+        smp, outs = diff.sample_ddim(B, torch.ones(n_classes), model_kwargs={"y": targets}, conditioning_function=cond)
+    kinds = [e[0] for e in log]
+    assert kinds == ["randn", "multinomial"] + ["randn_like"] * T_chain, kinds
+    out.update(sd_z0=log[0][1].numpy(), sd_y=outs["y"].numpy(), sd_sample=smp.numpy())
+    out["rev_sample"] = diff.gaussian_ddim_reverse_sample(x_data.clone(), T_chain, {}).numpy()
+    # multinomial_ddim_step with eta > 0, ragged categorical blocks
+    K = np.asarray([3, 7, 10, 2, 12], dtype=np.int64)
+    diffc, _ = build(K, 6, [128, 128], 16)
+    S = int(K.sum())
+    Bc = 64
+    oc = torch.randn((Bc, S), generator=g) * 1.5
+    zi = torch.stack([torch.randint(0, int(k), (Bc,), generator=g) for k in K], dim=1)
+    log_z = orc.log_onehot(zi, K)
+    md = {"md_K": K, "md_T": np.array(16), "md_out_cat": oc.numpy(), "md_z_idx": zi.numpy(), "md_eta": np.array(0.5)}
+    for t in (0, 1, 7, 15):
+        log = []
+        torch.manual_seed(40 + t)
+        with capture_rng(log):
+            res = diffc.multinomial_ddim_step(oc, log_z, torch.full((Bc,), t, dtype=torch.long), eta=0.5)
+        md[f"md_u_{t}"] = torch.cat([e[1] for e in log], dim=1).numpy()
+        md[f"md_idx_{t}"] = one_hot_to_idx(res, K)
+    out.update(md)
+    np.savez_compressed(os.path.join(OUT, f"ddimx_{tag}.npz"), **out)
+    print(f"ddim family {tag}: eta sample {tuple(out['eta_sample'].shape)}, reverse |x| {float(np.abs(out['rev_sample']).mean()):.3f}")
+
+
+def one_hot_to_idx(log_x: torch.Tensor, K) -> np.ndarray:
+    off = np.concatenate([[0], np.cumsum(K)])
+    return np.stack([log_x[:, off[k]:off[k + 1]].argmax(dim=1).numpy() for k in range(len(K))], axis=1)
+
+
 def gen_loader():
     """Batches of the reference's FastTensorDataLoader over two shuffled epochs (data_loaders.py:486-551)."""
     from midst_toolkit.models.clavaddpm.data_loaders import FastTensorDataLoader
@@ -606,6 +663,9 @@ def main():
     if "--loader-only" in sys.argv:
         gen_loader()
         return
+    if "--ddimx-only" in sys.argv:
+        gen_ddim_family()
+        return
     if "--ddim-only" in sys.argv:
         gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
         gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
@@ -630,6 +690,7 @@ def main():
             gen_kl(tag)
         gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
         gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
+        gen_ddim_family()
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
