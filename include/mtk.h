@@ -319,6 +319,27 @@ void mtk_clf_destroy(mtk_clf* clf);
 int mtk_clf_guidance(mtk_clf* clf, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,
                      float* logits, float* grad, mtk_stream stream);
 
+/* ---- TabSyn's EDM denoiser, forward only.  Replaces models/tabsyn/model/modules.py:
+ *   mtk_edm_forward  = MLPDiffusion.forward (modules.py:79-95): out = mlp(proj(x) + time_embed(swap(PositionalEmbedding(labels))))
+ *   mtk_edm_denoise  = Preconditioner.forward (modules.py:121-144): c_skip x + c_out F(c_in x, log(sigma) / 4)
+ *   mtk_edm_loss     = EDMLoss.__call__ around the Preconditioner (modules.py:165-185) on the caller's draws: rnd_normal [B]
+ *                      (torch.randn(B)) and noise [B, d_in] (torch.randn_like(data)); loss [B, d_in] = weight (D(y + n, sigma) - y)^2
+ * W / b: device fp32 PyTorch-layout weights in the order proj, time_embed.0, time_embed.2, mlp.0, mlp.2, mlp.4, mlp.6;
+ * freqs_host [dim_t / 2]: PositionalEmbedding's frequencies as the caller's torch computes them (modules.py:46-48).
+ * x / y: [B, ld] row-major fp32; labels / sigma: fp32, element r at [r * stride] (stride 0 broadcasts one value, as the
+ * TabSyn sampler's scalar t_hat does, utils.py:77); out / loss: [B, d_in] row-major fp32.  Calls on one object serialise on
+ * its workspaces. */
+typedef struct mtk_edm mtk_edm;
+int mtk_edm_create(int device, int d_in, int dim_t, const float* const* W, const float* const* b, const float* freqs_host,
+                   mtk_stream stream, mtk_edm** out);
+void mtk_edm_destroy(mtk_edm* edm);
+int mtk_edm_forward(mtk_edm* edm, int64_t B, const float* x, int64_t x_ld, const float* noise_labels, int64_t label_stride, float* out,
+                    mtk_stream stream);
+int mtk_edm_denoise(mtk_edm* edm, int64_t B, const float* x, int64_t x_ld, const float* sigma, int64_t sigma_stride, double sigma_data,
+                    float* out, mtk_stream stream);
+int mtk_edm_loss(mtk_edm* edm, int64_t B, const float* y, int64_t y_ld, const float* rnd_normal, const float* noise, double p_mean,
+                 double p_std, double sigma_data, float* loss, mtk_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

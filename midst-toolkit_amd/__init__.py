@@ -1,6 +1,7 @@
 """midst_toolkit_amd — MI355X-native diffusion hot path of midst-toolkit (drop-in classes)."""
 from .attack_features import AttackFeatureDriver  # noqa: F401
 from .classifier import Classifier, get_conditioning_function  # noqa: F401
+from . import tabsyn  # noqa: F401
 from .data import FastTensorDataLoader, endless  # noqa: F401
 from .diffusion import (  # noqa: F401
     FoundNaNsError,

@@ -62,6 +62,11 @@ _SIGS = {
     "mtk_clf_create": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     "mtk_clf_destroy": (None, [_p]),
     "mtk_clf_guidance": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, _p, _p, _p]),
+    "mtk_edm_create": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, C.POINTER(_p)]),
+    "mtk_edm_destroy": (None, [_p]),
+    "mtk_edm_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _p]),
+    "mtk_edm_denoise": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, C.c_double, _p, _p]),
+    "mtk_edm_loss": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, C.c_double, C.c_double, _p, _p]),
     "mtk_train_export": (C.c_int, [_p, _i32, _p, _p, _p]),
     "mtk_train_import": (C.c_int, [_p, _i32, _p, _p, _p]),
 }

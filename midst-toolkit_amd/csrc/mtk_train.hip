@@ -37,8 +37,9 @@ struct G2 {
     const float* emb; int emb_ld;  // optional [T][emb_ld], gathered by tvec[m]
     const int64_t* tvec; int64_t rows_valid; int T;  // per-row timesteps are clamped into [0, T) (mtk_tclamp)
     const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed (times neg_slope) where mask <= 0
-    int relu;
+    int relu;                      // 1: ReLU / LeakyReLU (neg_slope), 2: SiLU (x / (1 + exp(-x)), the TabSyn denoiser)
     float neg_slope;               // 0: ReLU; > 0: LeakyReLU slope, forward (relu != 0) and backward (mask != null) alike
+    const float* addend; int64_t add_rs;  // optional row-major [M][>= N] matrix added before the activation
     int atomic;                    // accumulate with fp32 atomic add (split-K)
     float* rowsum;                 // optional [M]: += sum_k A[m][k] (the bias gradient rides in the wgrad GEMM: the waves of
                                    // column tile 0 sum the A fragments they hold anyway; atomics, like C under split-K)
@@ -211,7 +212,9 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                     const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
                     v += g.emb[(int64_t)tr * g.emb_ld + n];
                 }
-                if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                if (g.addend) v += g.addend[row * g.add_rs + n];
+                if (g.relu == 2) v = v / (1.0f + expf(-v));
+                else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
                 if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v : g.neg_slope * v;
                 float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
                 if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
@@ -1059,4 +1062,212 @@ extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x
     hipLaunchKernelGGL(k_clf_copy_out, dim3(1024), dim3(256), 0, s, grad, (int64_t)c->D_in, c->d[cur], c->proj.in_pad, B, c->D_in);
     MTK_HIP(hipGetLastError());
     return mtk_poison_bad_t(t, B, c->T, grad, c->D_in, 1, c->D_in, nullptr, 0, 0, 0, nullptr, s);
+}
+
+
+// =================================================================================================================
+// TabSyn's EDM denoiser (models/tabsyn/model/modules.py:23-185): MLPDiffusion = proj(x) +
+// time_embed(swap(PositionalEmbedding(noise_labels))) followed by Linear/SiLU x 3 and a Linear head; Preconditioner
+// (c_skip, c_out, c_in, c_noise of Karras et al.) around it; EDMLoss on injected draws.  The noise label is a continuous
+// log-sigma, so the time embedding is computed per record (no table).  Forward only, on the fp32 MFMA GEMM above; the
+// element-wise preconditioning / loss is one fused kernel either side of the network.
+// =================================================================================================================
+struct mtk_edm {
+    int device = 0, d_in = 0, dim_t = 0;
+    MlpLayer proj, te0, te2, m[4];
+    float* freqs = nullptr;  // [dim_t / 2]
+    int64_t cap = 0;
+    float *xin = nullptr, *pe = nullptr, *e1 = nullptr, *emb = nullptr, *h = nullptr, *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *f = nullptr;
+    float *sig = nullptr;    // [cap] sigma per record (EDMLoss draws it)
+};
+
+namespace {
+
+// rows of the network input and of the positional embedding (modules.py:46-50, 90-91, 133-141).
+// mode 0: x_in = x (raw MLPDiffusion.forward, label = lab[row]);  mode 1: x_in = c_in * x, label = log(sigma) / 4 (Preconditioner);
+// mode 2: sigma = exp(rnd * p_std + p_mean), x_in = c_in * (y + noise * sigma) (EDMLoss then Preconditioner).
+struct EdmPre {
+    int mode, d_in, dim_t, in_pad, tp;
+    int64_t B, Mpad;
+    const float* x; int64_t x_ld;
+    const float* lab; int64_t lab_stride;   // noise labels (mode 0) / sigma (mode 1) / rnd_normal (mode 2); stride 0 broadcasts one value
+    const float* noise;                     // mode 2: [B][d_in]
+    float p_mean, p_std, sigma_data;
+    const float* freqs;
+    float *xin, *pe, *sig;
+};
+__global__ __launch_bounds__(256) void k_edm_pre(EdmPre a) {
+    const int half = a.dim_t / 2;
+    for (int64_t r = blockIdx.x; r < a.Mpad; r += gridDim.x) {
+        float sigma = 1.0f, label = 0.0f, c_in = 1.0f;
+        if (r < a.B) {
+            const float v = a.lab[r * a.lab_stride];
+            if (a.mode == 0) label = v;
+            else {
+                sigma = a.mode == 2 ? expf(v * a.p_std + a.p_mean) : v;
+                c_in = 1.0f / sqrtf(a.sigma_data * a.sigma_data + sigma * sigma);
+                label = logf(sigma) / 4.0f;
+            }
+            if (threadIdx.x == 0 && a.sig) a.sig[r] = sigma;
+        }
+        for (int j = threadIdx.x; j < a.in_pad; j += 256) {
+            float v = 0.0f;
+            if (r < a.B && j < a.d_in) {
+                v = a.x[r * a.x_ld + j];
+                if (a.mode == 2) v = v + a.noise[r * a.d_in + j] * sigma;
+                if (a.mode != 0) v = c_in * v;
+            }
+            a.xin[r * a.in_pad + j] = v;
+        }
+        for (int j = threadIdx.x; j < a.tp; j += 256) {  // [cos | sin] with the halves swapped = [sin | cos]
+            float v = 0.0f;
+            if (r < a.B && j < a.dim_t) {
+                const float arg = label * a.freqs[j < half ? j : j - half];
+                v = j < half ? sinf(arg) : cosf(arg);
+            }
+            a.pe[r * a.tp + j] = v;
+        }
+    }
+}
+// D = c_skip * x + c_out * F (modules.py:135-144); mode 2 also weight * (D - y)^2 (modules.py:178-185), x being y + n again.
+struct EdmPost {
+    int mode, d_in, f_ld;
+    int64_t B;
+    const float* x; int64_t x_ld;
+    const float* noise;
+    const float* sig; int64_t sig_stride;
+    float sigma_data;
+    const float* f;
+    float* out;
+};
+__global__ __launch_bounds__(256) void k_edm_post(EdmPost a) {
+    const int64_t n = a.B * a.d_in;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / a.d_in;
+        const int j = (int)(i - r * a.d_in);
+        const float fx = a.f[r * a.f_ld + j];
+        if (a.mode == 0) { a.out[i] = fx; continue; }
+        const float sigma = a.sig[r * a.sig_stride], sd = a.sigma_data;
+        const float y = a.x[r * a.x_ld + j];
+        const float x = a.mode == 2 ? y + a.noise[i] * sigma : y;
+        const float c_skip = (sd * sd) / (sigma * sigma + sd * sd);
+        const float c_out = sigma * sd / sqrtf(sigma * sigma + sd * sd);
+        const float d = c_skip * x + c_out * fx;
+        if (a.mode == 1) { a.out[i] = d; continue; }
+        const float w = (sigma * sigma + sd * sd) / ((sigma * sd) * (sigma * sd));
+        a.out[i] = w * ((d - y) * (d - y));
+    }
+}
+
+void edm_free_ws(mtk_edm* e) {
+    auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(e->xin); fr(e->pe); fr(e->e1); fr(e->emb); fr(e->h); fr(e->a0); fr(e->a1); fr(e->a2); fr(e->f); fr(e->sig);
+    e->cap = 0;
+}
+int edm_ensure_ws(mtk_edm* e, int64_t Mpad, hipStream_t s) {
+    if (Mpad <= e->cap) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    edm_free_ws(e);
+    auto al = [&](float*& p, int ld) { return hipMalloc(&p, sizeof(float) * (size_t)Mpad * ld); };
+    MTK_HIP(al(e->xin, e->proj.in_pad)); MTK_HIP(al(e->pe, e->te0.in_pad)); MTK_HIP(al(e->e1, e->te0.out_pad));
+    MTK_HIP(al(e->emb, e->te2.out_pad)); MTK_HIP(al(e->h, e->proj.out_pad)); MTK_HIP(al(e->a0, e->m[0].out_pad));
+    MTK_HIP(al(e->a1, e->m[1].out_pad)); MTK_HIP(al(e->a2, e->m[2].out_pad)); MTK_HIP(al(e->f, e->m[3].out_pad)); MTK_HIP(al(e->sig, 1));
+    e->cap = Mpad;
+    return MTK_OK;
+}
+int edm_linear(const MlpLayer& l, int64_t Mpad, const float* in, float* out, int act, const float* addend, int64_t add_rs, hipStream_t s) {
+    G2 g{};
+    g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
+    g.A = in; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad; g.C = out; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32;
+    g.relu = act; g.addend = addend; g.add_rs = add_rs;
+    return launch<false, false>(g, s);
+}
+
+// mode: see EdmPre.  lab: labels / sigma / rnd_normal with stride lab_stride.  out: [B][d_in] row-major.
+int edm_run(mtk_edm* e, int mode, int64_t B, const float* x, int64_t x_ld, const float* lab, int64_t lab_stride, const float* noise, double p_mean,
+            double p_std, double sigma_data, float* out, hipStream_t s) {
+    if (B == 0) return MTK_OK;
+    if (B > (1 << 22)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_edm: B = %lld above 4194304 rows per call", (long long)B);
+    MTK_HIP(hipSetDevice(e->device));
+    const int64_t Mpad = (B + TM - 1) / TM * TM;
+    int rc;
+    if ((rc = edm_ensure_ws(e, Mpad, s))) return rc;
+    EdmPre pa{mode, e->d_in, e->dim_t, e->proj.in_pad, e->te0.in_pad, B, Mpad, x, x_ld, lab, lab_stride, noise, (float)p_mean, (float)p_std,
+              (float)sigma_data, e->freqs, e->xin, e->pe, e->sig};
+    hipLaunchKernelGGL(k_edm_pre, dim3((unsigned)(Mpad < 4096 ? Mpad : 4096)), dim3(256), 0, s, pa);
+    if ((rc = edm_linear(e->te0, Mpad, e->pe, e->e1, 2, nullptr, 0, s))) return rc;                      // time_embed.0 + SiLU
+    if ((rc = edm_linear(e->te2, Mpad, e->e1, e->emb, 0, nullptr, 0, s))) return rc;                     // time_embed.2
+    if ((rc = edm_linear(e->proj, Mpad, e->xin, e->h, 0, e->emb, e->te2.out_pad, s))) return rc;         // proj(x) + emb (modules.py:94)
+    if ((rc = edm_linear(e->m[0], Mpad, e->h, e->a0, 2, nullptr, 0, s))) return rc;
+    if ((rc = edm_linear(e->m[1], Mpad, e->a0, e->a1, 2, nullptr, 0, s))) return rc;
+    if ((rc = edm_linear(e->m[2], Mpad, e->a1, e->a2, 2, nullptr, 0, s))) return rc;
+    if ((rc = edm_linear(e->m[3], Mpad, e->a2, e->f, 0, nullptr, 0, s))) return rc;
+    EdmPost po{mode, e->d_in, e->m[3].out_pad, B, x, x_ld, noise, e->sig, 1, (float)sigma_data, e->f, out};
+    hipLaunchKernelGGL(k_edm_post, dim3(1024), dim3(256), 0, s, po);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+}  // namespace
+
+extern "C" void mtk_edm_destroy(mtk_edm* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    clf_free_layer(e->proj); clf_free_layer(e->te0); clf_free_layer(e->te2);
+    for (auto& l : e->m) clf_free_layer(l);
+    if (e->freqs) (void)hipFree(e->freqs);
+    edm_free_ws(e);
+    delete e;
+}
+
+extern "C" int mtk_edm_create(int device, int d_in, int dim_t, const float* const* W, const float* const* b, const float* freqs_host,
+                              mtk_stream stream, mtk_edm** out) {
+    if (!out) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_create: out is null");
+    *out = nullptr;
+    if (d_in < 1 || d_in > 8192 || dim_t < 2 || dim_t > 4096 || (dim_t & 1) || !W || !b || !freqs_host) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_create: bad argument");
+    for (int i = 0; i < 7; ++i)
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_create: W[%d] or b[%d] is null", i, i);
+    int n_dev = 0;
+    MTK_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_create: device %d of %d", device, n_dev);
+    MTK_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    mtk_edm* e = new mtk_edm();
+    e->device = device; e->d_in = d_in; e->dim_t = dim_t;
+    const int tp = round_up(dim_t, TN), tp2 = round_up(2 * dim_t, TN);
+    int rc;
+    // weight order: 0 proj, 1 time_embed.0, 2 time_embed.2, 3..6 mlp.0 / mlp.2 / mlp.4 / mlp.6 (modules.py:64-77)
+    if ((rc = clf_make_layer(e->proj, d_in, dim_t, round_up(d_in, TN), W[0], b[0], s)) || (rc = clf_make_layer(e->te0, dim_t, dim_t, tp, W[1], b[1], s)) ||
+        (rc = clf_make_layer(e->te2, dim_t, dim_t, tp, W[2], b[2], s)) || (rc = clf_make_layer(e->m[0], dim_t, 2 * dim_t, tp, W[3], b[3], s)) ||
+        (rc = clf_make_layer(e->m[1], 2 * dim_t, 2 * dim_t, tp2, W[4], b[4], s)) || (rc = clf_make_layer(e->m[2], 2 * dim_t, dim_t, tp2, W[5], b[5], s)) ||
+        (rc = clf_make_layer(e->m[3], dim_t, d_in, tp, W[6], b[6], s))) {
+        mtk_edm_destroy(e);
+        return rc;
+    }
+    hipError_t he = hipMalloc(&e->freqs, sizeof(float) * (dim_t / 2));
+    if (he == hipSuccess) he = hipMemcpyAsync(e->freqs, freqs_host, sizeof(float) * (dim_t / 2), hipMemcpyHostToDevice, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) {
+        mtk_set_error("mtk_edm_create: %s", hipGetErrorString(he));
+        mtk_edm_destroy(e);
+        return MTK_ERR_HIP;
+    }
+    *out = e;
+    return MTK_OK;
+}
+
+extern "C" int mtk_edm_forward(mtk_edm* e, int64_t B, const float* x, int64_t x_ld, const float* noise_labels, int64_t label_stride, float* out,
+                               mtk_stream stream) {
+    if (!e || B < 0 || !x || !noise_labels || !out || x_ld < (e ? e->d_in : 0)) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_forward: bad argument");
+    return edm_run(e, 0, B, x, x_ld, noise_labels, label_stride, nullptr, 0.0, 0.0, 0.0, out, (hipStream_t)stream);
+}
+extern "C" int mtk_edm_denoise(mtk_edm* e, int64_t B, const float* x, int64_t x_ld, const float* sigma, int64_t sigma_stride, double sigma_data,
+                               float* out, mtk_stream stream) {
+    if (!e || B < 0 || !x || !sigma || !out || x_ld < (e ? e->d_in : 0) || !(sigma_data > 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_denoise: bad argument");
+    return edm_run(e, 1, B, x, x_ld, sigma, sigma_stride, nullptr, 0.0, 0.0, sigma_data, out, (hipStream_t)stream);
+}
+extern "C" int mtk_edm_loss(mtk_edm* e, int64_t B, const float* y, int64_t y_ld, const float* rnd_normal, const float* noise, double p_mean,
+                            double p_std, double sigma_data, float* loss, mtk_stream stream) {
+    if (!e || B < 0 || !y || !rnd_normal || !noise || !loss || y_ld < (e ? e->d_in : 0) || !(sigma_data > 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_loss: bad argument");
+    return edm_run(e, 2, B, y, y_ld, rnd_normal, 1, noise, p_mean, p_std, sigma_data, loss, (hipStream_t)stream);
 }

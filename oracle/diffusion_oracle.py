@@ -651,3 +651,67 @@ def affine_inverse(x: np.ndarray, kind: str, p0: np.ndarray, p1: np.ndarray) -> 
     else:
         raise ValueError(f"Unsupported normalization: {kind}")
     return x
+
+
+# --------------------------------------------------------------------------- TabSyn EDM denoiser (section 8f rank 4)
+def edm_names() -> list[str]:
+    """Parameter prefixes of TabSyn's MLPDiffusion in the C ABI's order (models/tabsyn/model/modules.py:64-77)."""
+    return ["proj", "time_embed.0", "time_embed.2", "mlp.0", "mlp.2", "mlp.4", "mlp.6"]
+
+
+def edm_forward(p: dict[str, torch.Tensor], x: torch.Tensor, noise_labels: torch.Tensor, dim_t: int) -> torch.Tensor:
+    """MLPDiffusion.forward (modules.py:79-95) with PositionalEmbedding (modules.py:46-50) written out."""
+    half = dim_t // 2
+    freqs = torch.arange(start=0, end=half, dtype=torch.float32) / half
+    freqs = (1 / 10000) ** freqs
+    ang = noise_labels.ger(freqs.to(noise_labels.dtype))
+    emb = torch.cat([ang.cos(), ang.sin()], dim=1)
+    emb = emb.reshape(emb.shape[0], 2, -1).flip(1).reshape(*emb.shape)
+    lin = lambda n, v: F.linear(v, p[n + ".weight"], p[n + ".bias"])  # noqa: E731
+    emb = lin("time_embed.2", F.silu(lin("time_embed.0", emb)))
+    h = lin("proj", x) + emb
+    h = F.silu(lin("mlp.0", h))
+    h = F.silu(lin("mlp.2", h))
+    h = F.silu(lin("mlp.4", h))
+    return lin("mlp.6", h)
+
+
+def edm_denoise(p: dict[str, torch.Tensor], x: torch.Tensor, sigma: torch.Tensor, dim_t: int, sigma_data: float = 0.5) -> torch.Tensor:
+    """Preconditioner.forward (modules.py:121-144)."""
+    x = x.to(torch.float32)
+    sigma = sigma.to(torch.float32).reshape(-1, 1)
+    c_skip = sigma_data**2 / (sigma**2 + sigma_data**2)
+    c_out = sigma * sigma_data / (sigma**2 + sigma_data**2).sqrt()
+    c_in = 1 / (sigma_data**2 + sigma**2).sqrt()
+    c_noise = sigma.log() / 4
+    f_x = edm_forward(p, (c_in * x).to(torch.float32), c_noise.flatten(), dim_t)
+    return c_skip * x + c_out * f_x.to(torch.float32)
+
+
+def edm_loss(p: dict[str, torch.Tensor], data: torch.Tensor, rnd_normal: torch.Tensor, noise: torch.Tensor, dim_t: int, p_mean: float = -1.2,
+             p_std: float = 1.2, sigma_data: float = 0.5) -> torch.Tensor:
+    """EDMLoss.__call__ (modules.py:165-185) on injected draws."""
+    sigma = (rnd_normal * p_std + p_mean).exp()
+    weight = (sigma**2 + sigma_data**2) / (sigma * sigma_data) ** 2
+    n = noise * sigma.unsqueeze(1)
+    d_yn = edm_denoise(p, data + n, sigma, dim_t, sigma_data)
+    return weight.unsqueeze(1) * ((d_yn - data) ** 2)
+
+
+def edm_sample(p: dict[str, torch.Tensor], latents: torch.Tensor, noises, dim_t: int, num_steps: int, sigma_data: float = 0.5) -> torch.Tensor:
+    """models/tabsyn/model/utils.py:20-87 (Euler-Heun sampler, S_churn = 1, rho = 7) on injected draws."""
+    sigma_min, sigma_max, rho_ = max(0.002, 0), min(80, float("inf")), 7
+    idx = torch.arange(num_steps, dtype=torch.float32)
+    t_steps = (sigma_max ** (1 / rho_) + idx / (num_steps - 1) * (sigma_min ** (1 / rho_) - sigma_max ** (1 / rho_))) ** rho_
+    t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])
+    x_next = latents.to(torch.float32) * t_steps[0]
+    for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+        gamma = min(1 / num_steps, np.sqrt(2) - 1)
+        t_hat = t_cur + gamma * t_cur
+        x_hat = x_next + (t_hat**2 - t_cur**2).sqrt() * 1 * noises[i]
+        d_cur = (x_hat - edm_denoise(p, x_hat, t_hat, dim_t, sigma_data)) / t_hat
+        x_next = x_hat + (t_next - t_hat) * d_cur
+        if i < num_steps - 1:
+            d_prime = (x_next - edm_denoise(p, x_next, t_next, dim_t, sigma_data)) / t_next
+            x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+    return x_next

@@ -87,6 +87,16 @@ def load_ddimx(tag: str = "A_numeric") -> dict:
     return d
 
 
+def load_edm(tag: str = "latent24") -> dict:
+    """Fixture of tools/make_golden.py::gen_edm: TabSyn's MLPDiffusion / Preconditioner / EDMLoss / sampler run by the reference."""
+    with np.load(os.path.join(GOLDEN, f"edm_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    for k in ("d_in", "dim_t", "num_steps"):
+        d[k] = int(d[k])
+    d["params"] = {k[2:]: tt(v) for k, v in d.items() if k.startswith("w_")}
+    return d
+
+
 def load_classifier(tag: str = "A_numeric") -> dict:
     """Fixture of tools/make_golden.py::gen_classifier: the reference's own Classifier (eval mode) and conditioning function."""
     with np.load(os.path.join(GOLDEN, f"classifier_{tag}.npz")) as z:

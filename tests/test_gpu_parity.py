@@ -436,6 +436,49 @@ def test_ddim_family():
         assert torch.equal(z_idx.cpu(), want), (t, int((z_idx.cpu() != want).sum()))
 
 
+def test_tabsyn_edm_denoiser():
+    """f4: TabSyn's EDM denoiser on HIP (mtk_edm_forward / mtk_edm_denoise / mtk_edm_loss) against the reference's own outputs
+    (tests/golden/edm_latent24.npz): MLPDiffusion.forward, Preconditioner.forward with per-row and scalar sigma, EDMLoss and
+    Model.forward on the reference's draws (<= 1e-4 relative to the row scale), and the Euler-Heun sampler with its draws injected
+    (a 10-step chain whose first sigma is 80: the bar is relative to the sample's scale)."""
+    from midst_toolkit_amd import tabsyn
+    from tests.helpers import load_edm
+
+    c = load_edm()
+    net = tabsyn.MLPDiffusion(c["d_in"], c["dim_t"])
+    net.load_state_dict(c["params"], strict=True)
+    net = net.to(dev())
+    mdl = tabsyn.Model(net)
+    x = tt(c["x"]).to(dev())
+
+    def near(got, want, rel=RTOL):
+        got, want = got.cpu().double(), want.double()
+        assert got.shape == want.shape
+        scale = want.abs().amax(dim=-1, keepdim=True).clamp_min(1e-3)
+        assert float(((got - want).abs() / scale).max()) <= rel, float(((got - want).abs() / scale).max())
+
+    with pytest.raises(NotImplementedError):
+        net(x, tt(c["labels"]).to(dev()))  # parameters require grad and autograd is on: the HIP path is forward only
+    with torch.no_grad():
+        near(net(x, tt(c["labels"]).to(dev())), tt(c["forward"]))
+        near(mdl.preconditioner(x, tt(c["sigma"]).to(dev())), tt(c["denoise"]))
+        near(mdl.preconditioner(x, torch.tensor(0.37)), tt(c["denoise_scalar"]))
+        inj = (tt(c["loss_rnd"]), tt(c["loss_noise"]))
+        near(mdl.loss_fn(mdl.preconditioner, x, inj), tt(c["loss"]))
+        assert abs(float(mdl(x, inj)) - float(c["loss_mean"])) <= RTOL * float(c["loss_mean"])
+        got = tabsyn.sample(mdl.preconditioner, x.shape[0], c["d_in"], num_steps=c["num_steps"], device=dev(),
+                            _injected={"latents": tt(c["s_latents"]), "noise": [tt(n) for n in c["s_noise"]]})
+        want = tt(c["s_sample"])
+        assert float((got.cpu() - want).abs().max()) <= 1e-3 * float(want.abs().max())
+        torch.manual_seed(5)
+        free = tabsyn.sample(mdl.preconditioner, 300, c["d_in"], num_steps=c["num_steps"], device=dev())  # not a tile multiple
+        assert free.shape == (300, c["d_in"]) and not bool(free.isnan().any())
+        # TabSyn's own shape (pipeline.py:141: dim_t = 1024) runs
+        big = tabsyn.MLPDiffusion(40, 1024).to(dev())
+        out = tabsyn.Preconditioner(big)(torch.randn((513, 40), device=dev()), torch.full((513,), 0.5, device=dev()))
+        assert out.shape == (513, 40) and not bool(out.isnan().any())
+
+
 def test_conditional_sample_rejects_categorical_tables():
     c = load_case("B_ragged")
     d = build(c, T=4)

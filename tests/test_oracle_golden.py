@@ -238,3 +238,27 @@ def test_ddim_family_bit_exact():
     for t in (0, 1, 7, 15):
         got = orc.multinomial_ddim_step(sm, c["md_K"], tt(c["md_out_cat"]), tt(c["md_z_idx"]), t, tt(c[f"md_u_{t}"]), eta=c["md_eta"])
         assert torch.equal(got, tt(c[f"md_idx_{t}"])), t
+
+
+def test_edm_restatement_bit_exact():
+    """TabSyn's EDM denoiser (models/tabsyn/model/modules.py:23-185, utils.py:20-87; tests/golden/edm_latent24.npz, generated by
+    running the reference): the oracle's MLPDiffusion.forward, Preconditioner.forward, EDMLoss and Euler-Heun sampler give the
+    reference's outputs bit for bit on the CPU that generated the fixture (1e-6 elsewhere: fp32 BLAS summation order)."""
+    from tests.helpers import load_edm
+
+    c = load_edm()
+    p, dt = c["params"], c["dim_t"]
+    x = tt(c["x"])
+
+    def same(got, want):
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+
+    same(orc.edm_forward(p, x, tt(c["labels"]), dt), tt(c["forward"]))
+    same(orc.edm_denoise(p, x, tt(c["sigma"]), dt), tt(c["denoise"]))
+    same(orc.edm_denoise(p, x, torch.tensor(0.37), dt), tt(c["denoise_scalar"]))
+    loss = orc.edm_loss(p, x, tt(c["loss_rnd"]), tt(c["loss_noise"]), dt)
+    same(loss, tt(c["loss"]))
+    assert abs(float(loss.mean(-1).mean()) - float(c["loss_mean"])) <= 1e-6 * float(c["loss_mean"])
+    got = orc.edm_sample(p, tt(c["s_latents"]), [tt(n) for n in c["s_noise"]], dt, c["num_steps"])
+    assert float((got - tt(c["s_sample"])).abs().max()) <= 1e-4 * float(tt(c["s_sample"]).abs().max())

@@ -544,6 +544,49 @@ def one_hot_to_idx(log_x: torch.Tensor, K) -> np.ndarray:
     return np.stack([log_x[:, off[k]:off[k + 1]].argmax(dim=1).numpy() for k in range(len(K))], axis=1)
 
 
+def gen_edm(tag="latent24", d_in=24, dim_t=128, B=96, num_steps=10):
+    """TabSyn's EDM denoiser (models/tabsyn/model/modules.py, utils.py) run by the reference: MLPDiffusion.forward, Preconditioner.forward
+    (per-row and scalar sigma), EDMLoss on captured draws, Model.forward, and the Euler-Heun sampler with every draw captured."""
+    from midst_toolkit.models.tabsyn.model import modules as tm
+    from midst_toolkit.models.tabsyn.model import utils as tu
+
+    torch.manual_seed(606)
+    net = tm.MLPDiffusion(d_in, dim_t)
+    mdl = tm.Model(net)
+    g = torch.Generator().manual_seed(607)
+    x = torch.randn((B, d_in), generator=g)
+    labels = torch.randn((B,), generator=g) * 0.8
+    sigma = (torch.randn((B,), generator=g) * 1.2 - 1.2).exp()
+    out = {"d_in": np.array(d_in), "dim_t": np.array(dim_t), "num_steps": np.array(num_steps), "x": x.numpy(), "labels": labels.numpy(),
+           "sigma": sigma.numpy()}
+    out.update({f"w_{k}": v.numpy() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        out["forward"] = net(x, labels).numpy()
+        out["denoise"] = mdl.preconditioner(x, sigma).numpy()
+        out["denoise_scalar"] = mdl.preconditioner(x, torch.tensor(0.37)).numpy()
+        log: list = []
+        torch.manual_seed(608)
+        with capture_rng(log):
+            loss = mdl.loss_fn(mdl.preconditioner, x)
+        assert [e[0] for e in log] == ["randn", "randn_like"]
+        out.update(loss_rnd=log[0][1].numpy(), loss_noise=log[1][1].numpy(), loss=loss.numpy(), loss_mean=np.array(float(loss.mean(-1).mean())))
+        log = []
+        torch.manual_seed(609)
+        import torch as _t
+        saved = tu.randn_like
+        tu.randn_like = lambda v: (log.append(("randn_like", saved(v))) or log[-1][1])
+        try:
+            with capture_rng(log):
+                smp = tu.sample(mdl.preconditioner, B, d_in, num_steps=num_steps, device=CPU)
+        finally:
+            tu.randn_like = saved
+        kinds = [e[0] for e in log]
+        assert kinds == ["randn"] + ["randn_like"] * num_steps, kinds
+        out.update(s_latents=log[0][1].numpy(), s_noise=np.stack([e[1].numpy() for e in log[1:]]), s_sample=smp.numpy())
+    np.savez_compressed(os.path.join(OUT, f"edm_{tag}.npz"), **out)
+    print(f"edm {tag}: loss mean {float(out['loss_mean']):.4f}, sample |x| {float(np.abs(out['s_sample']).mean()):.3f}")
+
+
 def gen_loader():
     """Batches of the reference's FastTensorDataLoader over two shuffled epochs (data_loaders.py:486-551)."""
     from midst_toolkit.models.clavaddpm.data_loaders import FastTensorDataLoader
@@ -663,6 +706,9 @@ def main():
     if "--loader-only" in sys.argv:
         gen_loader()
         return
+    if "--edm-only" in sys.argv:
+        gen_edm()
+        return
     if "--ddimx-only" in sys.argv:
         gen_ddim_family()
         return
@@ -691,6 +737,7 @@ def main():
         gen_ddim("A_numeric", [0], 8, [64, 64], 12, 48)
         gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
         gen_ddim_family()
+        gen_edm()
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
