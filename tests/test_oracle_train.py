@@ -77,8 +77,14 @@ def test_train_loop_matches_reference_on_the_berka_run():
     np.testing.assert_array_equal(flatten(p0, n).numpy()[:: c["stride"]], c["init_sample"])
     hist, p, ema = orc.train_loop(s, c["K"], c["Nn"], p0, c["batches"], float(c["lr"]), float(c["wd"]), c["steps"])
     ref = c["losses"]
-    assert np.all(np.abs(hist[:, 1] - ref[:, 1]) <= 1e-2 * np.abs(ref[:, 1]) + 1e-6), np.abs(hist[:, 1] - ref[:, 1]).max()
+    # The run is chaotic (see tests/test_gpu_train.py::test_berka_run_200_steps: a 1e-7 perturbation of the initial weights moves
+    # the reference's own curve by up to 3.3e-2, mean 6.4e-3, and its weights by up to 1.6e-2): in a fresh process on the CPU that
+    # made the fixture the oracle reproduces all of it bit for bit, but another thread count (set by an earlier test) or another
+    # host's fp32 BLAS summation order is such a perturbation.  Bars: the first 10 losses tight, the rest within twice that floor.
+    rel = np.abs(hist[:, 1] - ref[:, 1]) / np.abs(ref[:, 1])
+    assert rel[:10].max() <= 1e-5, rel[:10]
+    assert rel.max() <= 6.6e-2 and rel.mean() <= 1.3e-2, (rel.max(), rel.mean())
     assert np.all(hist[:, 0] == 0.0)
-    lr = float(c["lr"])
-    assert np.abs(flatten(p, n).numpy()[:: c["stride"]] - c["final_sample"]).max() <= 8 * lr
-    assert np.abs(flatten(ema, n).numpy()[:: c["stride"]] - c["ema_sample"]).max() <= 8 * lr * 1e-3 * c["steps"]
+    err = np.abs(flatten(p, n).numpy()[:: c["stride"]] - c["final_sample"])
+    assert err.max() <= 3.2e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+    assert np.abs(flatten(ema, n).numpy()[:: c["stride"]] - c["ema_sample"]).max() <= 3.2e-2 * 0.2
