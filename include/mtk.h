@@ -275,6 +275,15 @@ int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, cons
  * time-embedding scatter accumulates in 64-bit fixed point, so gradients are bit-identical run to run; off = fp32 hardware
  * atomics (order varies). */
 int mtk_train_set_deterministic(mtk_ctx* ctx, int on);
+/* No reference counterpart (the reference trains on one device; north_star part 1 / SURVEY 2c "bucketed per layer, overlapped"):
+ * data-parallel overlap of the gradient exchange with the backward.  The gradient image falls into buckets in the order the
+ * backward completes them - head, hidden layers last to first, proj, time-embedding MLP.  mtk_train_bucket_layout returns their
+ * number and, when off / len are given, each bucket's element offset and length inside one image.  mtk_train_set_bucket_events
+ * hands the library one hipEvent_t per bucket (n = 0 clears): mtk_train_step / mtk_train_backward then record event i on their
+ * stream as soon as bucket i of the gradient image is final, so the caller can all-reduce that slice on another stream
+ * (RCCL) while the rest of the backward runs.  Values are those of the unbucketed call, bit for bit. */
+int mtk_train_bucket_layout(mtk_ctx* ctx, int max_buckets, int64_t* off, int64_t* len);
+int mtk_train_set_bucket_events(mtk_ctx* ctx, int n, void* const* events);
 /* The two halves of mtk_train_step as separate calls: the autograd seam of the drop-in's mixed_loss (TRAINER:89-91 calls
  * mixed_loss and then .backward() on the sum of its two scalars; attacks/ensemble/clavaddpm_fine_tuning.py does the same).
  * mtk_train_forward = noising + denoiser forward with every activation kept + per-record losses.  mtk_train_backward fills

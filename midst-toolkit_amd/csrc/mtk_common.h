@@ -59,6 +59,9 @@ struct TrainState {
     float* state = nullptr;  // caller-owned, 5 * n_img floats
     size_t n_img = 0;
     std::vector<TrainLayerRef> layers;  // proj, temb0, temb2, blocks..., head
+    // data-parallel overlap: one event per gradient bucket (head, blocks last..first, proj, time-embedding MLP), recorded on the
+    // compute stream when that bucket of the gradient image is final (mtk_train_set_bucket_events); empty: no events
+    std::vector<hipEvent_t> bucket_events;
     // time-embedding tables kept for the backward pass, [Tpad][tpad]
     float *sin_tab = nullptr, *z0_tab = nullptr, *e1_tab = nullptr, *demb = nullptr, *dtab = nullptr;
     int Tpad = 0;

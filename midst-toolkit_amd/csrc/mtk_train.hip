@@ -645,6 +645,27 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         }
         return launcher(g);
     };
+    // Gradient buckets in the order the backward finishes them: 0 head, 1.. blocks last to first, then proj, then the
+    // time-embedding MLP.  With bucket events set (data-parallel training), a bucket's split-batch partials are added
+    // right away (instead of by the one launch at the end) and its event is recorded: the caller's all-reduce of that
+    // slice of the gradient image runs on another stream under the rest of the backward.
+    int seg_mark = 0, bucket = 0;
+    const bool bucketed = !tr.bucket_events.empty();
+    auto bucket_done = [&]() -> int {
+        if (!bucketed) return MTK_OK;
+        if (segs.n > seg_mark) {
+            ReduceSegs part;
+            part.n = segs.n - seg_mark;
+            for (int i = 0; i < part.n; ++i) {
+                part.dst[i] = segs.dst[seg_mark + i]; part.slab[i] = segs.slab[seg_mark + i];
+                part.splits[i] = segs.splits[seg_mark + i]; part.n4[i] = segs.n4[seg_mark + i];
+            }
+            hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)part.n), dim3(256), 0, s, part);
+            seg_mark = segs.n;
+        }
+        MTK_HIP(hipEventRecord(tr.bucket_events[bucket++], s));
+        return MTK_OK;
+    };
     {   // head: dW[o][k] = sum_m dout[o][m] act[m][k];  db = row sums;  d act = dout^T W  masked by act > 0
         MlpLayer& l = c->head;
         TrainLayerRef& r = ref_of(&l);
@@ -654,6 +675,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.c_rs = l.in_pad; g.c_cs = 1;
         if ((rc = wgrad(g, [&](const G2& q) { return launch<false, true>(q, s); }, grads + r.w_off, nullptr))) return rc;
         hipLaunchKernelGGL(k_rowsum_cm, dim3(l.out), dim3(256), 0, s, tr.dout, ld, Mpad, grads + r.b_off);
+        if ((rc = bucket_done())) return rc;
         G2 d{};
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = tr.dout; d.lda = ld; d.B = l.w32; d.ldb = l.in_pad;
@@ -672,6 +694,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.c_rs = l.in_pad; g.c_cs = 1;
         // db[o] = sum_m dy[m][o] rides along
         if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = bucket_done())) return rc;
         G2 d{};
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
@@ -689,6 +712,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
         g.c_rs = l.in_pad; g.c_cs = 1;
         if ((rc = wgrad(g, [&](const G2& q) { return launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = bucket_done())) return rc;
         if (tr.deterministic) {
             const int64_t ne = (int64_t)tr.Tpad * c->emb_ld;
             MTK_HIP(hipMemsetAsync(tr.demb_fix, 0, sizeof(long long) * (size_t)ne, s));
@@ -716,9 +740,52 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.slab = nullptr; g.rowsum_slab = nullptr;
         if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r0.w_off, grads + r0.b_off))) return rc;
     }
-    if (segs.n > 0)  // every split-batch partial of the iteration, added in slice order by one launch
+    if (bucketed) {
+        if ((rc = bucket_done())) return rc;
+    } else if (segs.n > 0) {  // every split-batch partial of the iteration, added in slice order by one launch
         hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)segs.n), dim3(256), 0, s, segs);
+    }
     MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+// Gradient buckets of the image in the order the backward completes them (see train_phases): element offset and length
+// of each inside one image.  Layers sit in the image as [W | b] in the order proj, temb0, temb2, blocks..., head.
+extern "C" int mtk_train_bucket_layout(mtk_ctx* c, int max_buckets, int64_t* off, int64_t* len) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_bucket_layout: null context");
+    if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_bucket_layout: call mtk_train_attach first");
+    TrainState& tr = c->train;
+    const int nl = (int)tr.layers.size(), nb = nl - 1;  // temb0 and temb2 share a bucket
+    if (!off || !len) return nb;
+    if (max_buckets < nb) MTK_FAIL(MTK_ERR_ARG, "mtk_train_bucket_layout: %d buckets, room for %d", nb, max_buckets);
+    auto span = [&](int first, int last, int b) {
+        off[b] = (int64_t)tr.layers[first].w_off;
+        len[b] = (int64_t)(tr.layers[last].b_off + tr.layers[last].l->out_pad) - off[b];
+    };
+    int b = 0;
+    for (int i = nl - 1; i >= 3; --i) span(i, i, b++);  // head, blocks last to first
+    span(0, 0, b++);                                     // proj
+    span(1, 2, b++);                                     // time-embedding MLP
+    return nb;
+}
+
+extern "C" int mtk_train_set_bucket_events(mtk_ctx* c, int n, void* const* events) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_bucket_events: null context");
+    if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_set_bucket_events: call mtk_train_attach first");
+    TrainState& tr = c->train;
+    if (n == 0 || !events) {
+        tr.bucket_events.clear();
+        return MTK_OK;
+    }
+    if (n != (int)tr.layers.size() - 1) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_bucket_events: %d events for %d buckets", n, (int)tr.layers.size() - 1);
+    tr.bucket_events.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        if (!events[i]) {
+            tr.bucket_events.clear();
+            MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_bucket_events: event %d is null", i);
+        }
+        tr.bucket_events[i] = (hipEvent_t)events[i];
+    }
     return MTK_OK;
 }
 

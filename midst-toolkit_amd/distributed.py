@@ -103,3 +103,52 @@ def allreduce_gradients(grad_image: Tensor) -> None:
     contribution by 1 / global batch in mtk_train_step)."""
     if world()[1] > 1:
         dist.all_reduce(grad_image)
+
+
+class BucketedGradientExchange:
+    """The gradient exchange of data-parallel training, one all-reduce per gradient bucket, overlapped with the backward
+    (north_star part 1).  The library records an event per bucket as the backward finishes it
+    (mtk_train_set_bucket_events); ``launch()`` - called right after the asynchronous backward call returns, while the GPU is
+    still working through it - queues on a side stream, bucket by bucket in completion order, "wait for the bucket's event, then
+    all-reduce (RCCL) that slice of the gradient image"; ``wait()`` makes the compute stream wait for the side stream before the
+    optimizer kernel reads the image.  The sums are those of the single blocking all-reduce of the whole image: the same
+    elements are added across the same ranks, only in several calls.
+
+    On a CPU image or with the gloo backend (tests; two ranks sharing one GPU) the same bucket loop runs blocking."""
+
+    def __init__(self, engine, grad_image: Tensor, layout: list[tuple[int, int]] | None = None):
+        self.image = grad_image
+        self.layout = layout if layout is not None else (engine.train_bucket_layout() if engine is not None else [(0, grad_image.numel())])
+        self.world = world()[1]
+        self.overlapped = bool(self.world > 1 and grad_image.is_cuda and dist.get_backend() == "nccl")
+        self.engine = engine
+        self.events = None
+        self.stream = None
+        if self.overlapped:
+            self.events = [torch.cuda.Event() for _ in self.layout]
+            engine.train_set_bucket_events(self.events)
+            self.stream = torch.cuda.Stream(device=grad_image.device)
+
+    def launch(self) -> None:
+        if self.world == 1:
+            return
+        if not self.overlapped:
+            if self.image.is_cuda:
+                torch.cuda.synchronize(self.image.device)
+            for off, ln in self.layout:
+                dist.all_reduce(self.image[off:off + ln])
+            return
+        with torch.cuda.stream(self.stream):
+            for ev, (off, ln) in zip(self.events, self.layout):
+                self.stream.wait_event(ev)
+                dist.all_reduce(self.image[off:off + ln])
+
+    def wait(self) -> None:
+        if self.overlapped:
+            torch.cuda.current_stream(self.image.device).wait_stream(self.stream)
+
+    def close(self) -> None:
+        if self.overlapped and self.engine is not None:
+            torch.cuda.synchronize(self.image.device)
+            self.engine.train_set_bucket_events(None)
+            self.overlapped = False

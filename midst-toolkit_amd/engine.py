@@ -228,6 +228,32 @@ class Engine:
             check(_lib.lib().mtk_train_step(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), float(inv_global_batch),
                                             ptr(loss_multi), ptr(loss_gauss), seed, row0, self._stream()))
 
+    def train_bucket_layout(self) -> list[tuple[int, int]]:
+        """(offset, length) of each gradient bucket inside one image, in the order the backward completes them: head, hidden
+        layers last to first, proj, time-embedding MLP (mtk_train_bucket_layout)."""
+        n = int(_lib.lib().mtk_train_bucket_layout(self._h, 0, None, None))
+        if n < 0:
+            check(n)
+        off, ln = (C.c_int64 * n)(), (C.c_int64 * n)()
+        rc = int(_lib.lib().mtk_train_bucket_layout(self._h, n, off, ln))
+        if rc < 0:
+            check(rc)
+        return [(int(off[i]), int(ln[i])) for i in range(n)]
+
+    def train_set_bucket_events(self, events) -> None:
+        """``events``: one torch.cuda.Event per gradient bucket (None clears).  The backward records event i on its stream when
+        bucket i of the gradient image is final.  The events are kept alive here for as long as the library holds their handles."""
+        if not events:
+            check(_lib.lib().mtk_train_set_bucket_events(self._h, 0, None))
+            self._bucket_events = None
+            return
+        with torch.cuda.device(self.device):
+            for e in events:
+                e.record()  # torch creates the hipEvent_t lazily: after one record() the handle exists
+        handles = (C.c_void_p * len(events))(*[int(e.cuda_event) for e in events])
+        check(_lib.lib().mtk_train_set_bucket_events(self._h, len(events), handles))
+        self._bucket_events = list(events)
+
     def train_set_deterministic(self, on: bool) -> None:
         """True (default): fixed-order reductions, gradients bit-identical run to run; False: fp32 hardware atomics."""
         check(_lib.lib().mtk_train_set_deterministic(self._h, int(bool(on))))

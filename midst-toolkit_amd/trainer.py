@@ -17,7 +17,7 @@ import torch
 from torch import Tensor, nn
 
 from .diffusion import GaussianMultinomialDiffusion
-from .distributed import allreduce_gradients, world
+from .distributed import BucketedGradientExchange, world
 from .model import timestep_frequencies
 
 
@@ -63,6 +63,8 @@ class ClavaDDPMTrainer:
         self._engine = diffusion_model.engine()
         self.state = self._engine.train_attach(timestep_frequencies(net.timestep_dimension))
         self._rank, self._world = world()
+        # data parallel: one all-reduce per gradient bucket, issued under the backward (distributed.BucketedGradientExchange)
+        self._exchange = BucketedGradientExchange(self._engine, self.state[1]) if self._world > 1 else None
 
     # ------------------------------------------------------------------ TRAINER:58
     def _anneal_learning_rate(self, step: int) -> None:
@@ -94,7 +96,9 @@ class ClavaDDPMTrainer:
         lm = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None
         lg = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None
         eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
-        allreduce_gradients(self.state[1])  # the one exchange of an iteration
+        if self._exchange is not None:  # the one exchange of an iteration, bucket by bucket under the backward
+            self._exchange.launch()
+            self._exchange.wait()
         g = self.optimizer.param_groups[0]
         self.optimizer.steps_done += 1
         eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
@@ -147,6 +151,8 @@ class ClavaDDPMTrainer:
         """Detach the training state: the denoiser is re-packed (fp32 + bf16 images) on its next use."""
         self.sync_modules()
         self.diffusion_model._denoise_fn._synced_key = None
+        if self._exchange is not None:
+            self._exchange.close()
 
 
 def update_ema(target_params: Iterator[nn.Parameter], source_params: Iterator[nn.Parameter], rate: float = 0.999) -> None:

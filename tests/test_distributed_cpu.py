@@ -109,6 +109,28 @@ def test_data_parallel_gradient_is_the_global_batch_gradient():
     assert out[0] < 1e-5 and out[1] < 1e-5, out
 
 
+def _bucket_rank(rank, ws):
+    import midst_toolkit_amd.distributed as D
+
+    g = torch.Generator().manual_seed(100 + rank)
+    image = torch.randn((40_000,), generator=g)
+    layout = [(33_000, 7_000), (20_000, 13_000), (4_096, 15_904), (0, 4_096)]  # completion order: head first, proj side last
+    blocking = image.clone()
+    D.allreduce_gradients(blocking)
+    ex = D.BucketedGradientExchange(None, image, layout=layout)
+    assert not ex.overlapped and ex.world == ws
+    ex.launch()
+    ex.wait()
+    return bool(torch.equal(image, blocking))
+
+
+def test_bucketed_gradient_exchange_equals_the_blocking_all_reduce():
+    """the per-bucket exchange (what the trainer issues under the backward on the GPU; here its blocking
+    form over gloo) leaves the gradient image bit-identical to the single all-reduce of the whole image."""
+    out = run_ranks(_bucket_rank, 2)
+    assert out == {0: True, 1: True}, out
+
+
 class _FakeSampler:
     """Stands in for the drop-in diffusion object in the host-logic test of sample_all_sharded (no GPU in this tier):
     same sample_all signature; in "philox" mode a row is a pure function of (seed, global row index), as the kernels'

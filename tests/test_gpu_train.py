@@ -278,6 +278,43 @@ def test_berka_run_200_steps():
     assert float(np.abs(ema - c["ema_sample"]).max()) <= 3.2e-2 * 0.2
 
 
+def test_bucket_events_leave_the_gradients_unchanged():
+    """mtk_train_set_bucket_events: with one event per gradient bucket the backward adds each bucket's split-batch partials as it
+    goes and records the bucket's event; the gradient image is bit-identical to the unbucketed call, the layout tiles the image in
+    completion order, and a side stream that waits on each event and touches only that bucket sees final values."""
+    c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[256, 128, 128])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    B = 3000
+    x0, t, eps, u = [v.to(dev()) for v in big_batch(c, B)]
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    eng.train_step(x0, t, eps, u, 1.0 / B, None, None)
+    torch.cuda.synchronize()
+    plain = tr.state[1].clone()
+    layout = eng.train_bucket_layout()
+    assert len(layout) == len(c["d_layers"]) + 3
+    spans = sorted(layout)
+    assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == tr.state.shape[1]
+    assert layout[0][0] == max(o for o, _ in layout)  # the head sits last in the image and completes first
+    events = [torch.cuda.Event() for _ in layout]
+    eng.train_set_bucket_events(events)
+    side = torch.cuda.Stream()
+    copies = []
+    eng.train_step(x0, t, eps, u, 1.0 / B, None, None)
+    with torch.cuda.stream(side):
+        for ev, (off, ln) in zip(events, layout):
+            side.wait_event(ev)
+            copies.append((off, ln, tr.state[1][off:off + ln].clone()))
+    torch.cuda.synchronize()
+    assert torch.equal(tr.state[1], plain)
+    for off, ln, cp in copies:
+        assert torch.equal(cp, plain[off:off + ln]), (off, ln)
+    eng.train_set_bucket_events(None)
+    eng.train_step(x0, t, eps, u, 1.0 / B, None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.state[1], plain)
+
+
 def _two_rank_body(rank, ws, q):
     import os
 
@@ -304,6 +341,14 @@ def _two_rank_body(rank, ws, q):
         D.allreduce_gradients(tr.state[1])
         got = export(tr, "grads")
         worst = max(float((got[k] - full[k]).norm() / full[k].norm().clamp_min(1e-30)) for k in full)
+        # the same exchange bucket by bucket (what the trainer does; over gloo its blocking form): identical sums
+        eng.train_step(x0[lo:hi], t[lo:hi].contiguous(), eps[lo:hi], u[lo:hi], 1.0 / B, None, None, row0=lo)
+        ex = D.BucketedGradientExchange(eng, tr.state[1])
+        ex.launch()
+        ex.wait()
+        again = export(tr, "grads")
+        if not all(bool(torch.equal(again[k], got[k])) for k in got):
+            worst = float("inf")
         q.put((rank, worst))
     finally:
         dist.destroy_process_group()
