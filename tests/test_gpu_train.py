@@ -379,6 +379,57 @@ def test_two_rank_training_gradient():
     assert res[0] < 2e-5 and res[1] < 2e-5, res
 
 
+def _two_rank_sampling_body(rank, ws, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK=str(rank), WORLD_SIZE=str(ws))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import midst_toolkit_amd as mtk
+        import midst_toolkit_amd.distributed as D
+
+        K, Nn, T, N = np.asarray([3, 7, 10, 2, 12]), 6, 12, 301
+        torch.manual_seed(0)  # every process seeded alike, as the reference pipeline does
+        net = mtk.MLPDiffusion(Nn + int(K.sum()), 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+        d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev()).to(dev())
+        d.rng = "philox"
+        torch.manual_seed(1234)
+        x, y = D.sample_all_sharded(d, N, 128, torch.ones(1))
+        # the same seed on one device, all rows: what a single-GPU run of the sharded call draws
+        torch.manual_seed(1234)
+        seed = int(torch.randint(1, 2**62, (1,), dtype=torch.int64).item())
+        full, _ = d.sample_all(N, 128, torch.ones(1), row0=0, seed=seed)
+        q.put((rank, (tuple(x.shape), bool(torch.equal(x, full)), int(x.isnan().sum()))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sampling_equals_the_single_device_rows():
+    """sample_all_sharded on two ranks (sharing the test box's one GPU, gloo gather): with rng = "philox" the gathered table is,
+    row for row and bit for bit, what one device draws for the same seed - the samples do not depend on the number of GPUs."""
+    import os
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_two_rank_sampling_body, args=(r, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        assert p.exitcode == 0, p.exitcode
+    res = dict(q.get() for _ in range(2))
+    assert res[0] == ((301, 11), True, 0) and res[1] == ((301, 11), True, 0), res
+
+
 @pytest.mark.parametrize("tag", ["B_ragged", "A_numeric"])
 def test_reference_trainer_loop_runs_against_the_drop_in(tag):
     """The reference's own training loop, statement for statement (TRAINER:39-51 set-up, :70-94 _train_step, :58-68 anneal,
