@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=50)
     ap.add_argument("--rng", default="philox", help="philox: in-kernel noise; torch: the reference's draws (the drop-in default)")
     ap.add_argument("--train-only", action="store_true")
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"], help="bf16: bf16 operands / fp32 accumulation in the iteration's GEMMs")
     ap.add_argument("--atomics", action="store_true", help="fp32 atomic reductions instead of the deterministic fixed-order ones")
     a = ap.parse_args()
     import midst_toolkit_amd as mtk
@@ -70,6 +71,7 @@ def main():
     tr = mtk.ClavaDDPMTrainer(d, batches(), 2e-4, 1e-4, a.train_steps, device=dev)
     tr.log_every = 10**9
     tr._engine.train_set_deterministic(not a.atomics)
+    tr._engine.train_set_precision(a.train_precision)
     for _ in range(6):
         tr._train_step(x0)
     torch.cuda.synchronize()
@@ -79,7 +81,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.train_steps
     fl_step = a.batch * (3 * fl_fwd - 2 * D * 128)
-    print(json.dumps({"measure": "training iteration", "precision": "fp32", "reductions": "atomics" if a.atomics else "deterministic", "rng": a.rng, "hidden": a.hidden, "batch": a.batch, "ms_per_step": dt * 1e3,
+    print(json.dumps({"measure": "training iteration", "precision": a.train_precision, "reductions": "atomics" if a.atomics else "deterministic", "rng": a.rng, "hidden": a.hidden, "batch": a.batch, "ms_per_step": dt * 1e3,
                       "rows_per_s": a.batch / dt, "TFLOPs": fl_step / dt / 1e12, "frac_of_f32_mfma_peak": fl_step / dt / 1e12 / 157.3}), flush=True)
 
 

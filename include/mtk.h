@@ -275,6 +275,11 @@ int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, cons
  * time-embedding scatter accumulates in 64-bit fixed point, so gradients are bit-identical run to run; off = fp32 hardware
  * atomics (order varies). */
 int mtk_train_set_deterministic(mtk_ctx* ctx, int on);
+/* No reference counterpart (the reference trains in fp32; north_star part 1 "bf16 / fp32 accumulate"): MTK_PREC_BF16 makes every
+ * GEMM of the training iteration (forward, data gradients, weight gradients) round its operands to bf16 and multiply on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the master weights, the gradient image, AdamW and EMA stay fp32.
+ * MTK_PREC_FP32 (default) is the parity path.  Stated tolerance: tests/test_gpu_train.py. */
+int mtk_train_set_precision(mtk_ctx* ctx, int precision);
 /* No reference counterpart (the reference trains on one device; north_star part 1 / SURVEY 2c "bucketed per layer, overlapped"):
  * data-parallel overlap of the gradient exchange with the backward.  The gradient image falls into buckets in the order the
  * backward completes them - head, hidden layers last to first, proj, time-embedding MLP.  mtk_train_bucket_layout returns their

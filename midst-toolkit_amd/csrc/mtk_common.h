@@ -62,6 +62,7 @@ struct TrainState {
     // data-parallel overlap: one event per gradient bucket (head, blocks last..first, proj, time-embedding MLP), recorded on the
     // compute stream when that bucket of the gradient image is final (mtk_train_set_bucket_events); empty: no events
     std::vector<hipEvent_t> bucket_events;
+    int bf16 = 0;  // mtk_train_set_precision: the iteration's GEMMs round their operands to bf16 (fp32 accumulate, fp32 master weights)
     // time-embedding tables kept for the backward pass, [Tpad][tpad]
     float *sin_tab = nullptr, *z0_tab = nullptr, *e1_tab = nullptr, *demb = nullptr, *dtab = nullptr;
     int Tpad = 0;

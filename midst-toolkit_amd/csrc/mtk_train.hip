@@ -47,6 +47,7 @@ struct G2 {
     // (rowsum_slab + z * M) with plain stores; k_reduce_splits then adds the slices in order.  Replaces the atomics.
     float* slab; int64_t slab_stride;
     float* rowsum_slab;
+    int bf16;                      // operands rounded to bf16 on their way from LDS to the MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
 };
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
@@ -124,7 +125,20 @@ struct TileMover {
 
 // WT = 2: 128 x 128 workgroup tile (each wave 2 x 2 MFMA tiles); WT = 1: 64 x 64 (each wave one 32 x 32 tile), used when
 // the larger tile would leave the chip with fewer than two workgroups per CU.
-template <bool AT, bool BT, int WT>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t to_bf16x8(const float* f) {
+    bf16x8_t v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
+    return v;
+}
+
+// BF (mixed-precision training, mtk_train_set_precision): same tiles, same fp32 operands in memory and LDS, same fp32
+// accumulators and epilogue - only the product changes.  A lane holds 16 consecutive k of its row per k-block; as fp32
+// they feed sixteen v_mfma_f32_32x32x2f32, rounded to bf16 they are the operands of two v_mfma_f32_32x32x16_bf16 (any
+// assignment of k values to lanes is valid as long as both operands use the same one).  Master weights, gradients,
+// AdamW and EMA stay fp32.
+template <bool AT, bool BT, int WT, bool BF>
 __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
     constexpr int T = 64 * WT;
     constexpr int TILE_FLOATS = T * LDN > TK * (T + 4) ? T * LDN : TK * (T + 4);
@@ -176,13 +190,29 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 rs[mt] += t0 + t1;
             }
         }
+        if constexpr (BF) {
+            bf16x8_t ab[WT][2], bb[WT][2];
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int q = 0; q < WT; ++q) {
+                ab[q][0] = to_bf16x8(a[q]); ab[q][1] = to_bf16x8(a[q] + 8);
+                bb[q][0] = to_bf16x8(b[q]); bb[q][1] = to_bf16x8(b[q] + 8);
+            }
 #pragma unroll
-            for (int mt = 0; mt < WT; ++mt)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int nt = 0; nt < WT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < WT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[mt][h], bb[nt][h], acc[mt][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < WT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+        }
         __syncthreads();
     }
     if (sum_rows) {  // lanes l and l + 32 hold the two k-halves of row (lane & 31)
@@ -226,10 +256,13 @@ template <bool AT, bool BT>
 int launch(const G2& g, hipStream_t s) {
     const int splits = (g.K + g.kchunk - 1) / g.kchunk;
     const int64_t wg128 = (int64_t)(g.M / TM) * ((g.N + TN - 1) / TN) * splits;
+    const dim3 g128((unsigned)(g.M / 128), (unsigned)((g.N + 127) / 128), (unsigned)splits), g64((unsigned)(g.M / 64), (unsigned)((g.N + 63) / 64), (unsigned)splits);
     if (wg128 >= 512) {
-        hipLaunchKernelGGL((k_gemm2<AT, BT, 2>), dim3((unsigned)(g.M / 128), (unsigned)((g.N + 127) / 128), (unsigned)splits), dim3(256), 0, s, g);
+        if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 2, true>), g128, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm2<AT, BT, 2, false>), g128, dim3(256), 0, s, g);
     } else {
-        hipLaunchKernelGGL((k_gemm2<AT, BT, 1>), dim3((unsigned)(g.M / 64), (unsigned)((g.N + 63) / 64), (unsigned)splits), dim3(256), 0, s, g);
+        if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 1, true>), g64, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm2<AT, BT, 1, false>), g64, dim3(256), 0, s, g);
     }
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -581,6 +614,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     if ((rc = mtk_q_sample(c, B, x0, x0_ld, t, eps, u, tr.xin, 1, ld, tr.xt_idx, seed, row0, stream))) return rc;
     {
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = (int)Mpad; g.N = c->proj.out_pad; g.K = c->proj.in_pad; g.kchunk = g.K;
         g.A = tr.xin; g.lda = ld; g.B = c->proj.w32; g.ldb = c->proj.in_pad;
         g.C = tr.act[0]; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
@@ -590,6 +624,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     for (size_t i = 0; i < c->blocks.size(); ++i) {
         MlpLayer& l = c->blocks[i];
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
         g.A = tr.act[i]; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
         g.C = tr.act[i + 1]; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32; g.relu = 1;
@@ -598,6 +633,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     {
         MlpLayer& l = c->head;
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = (int)Mpad; g.N = l.out; g.K = l.in_pad; g.kchunk = g.K;
         g.A = tr.act.back(); g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
         g.C = tr.out; g.c_rs = 1; g.c_cs = ld; g.bias = l.b32;
@@ -670,6 +706,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         MlpLayer& l = c->head;
         TrainLayerRef& r = ref_of(&l);
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = tr.dout; g.lda = ld; g.B = tr.act.back(); g.ldb = l.in_pad;
         g.c_rs = l.in_pad; g.c_cs = 1;
@@ -677,6 +714,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         hipLaunchKernelGGL(k_rowsum_cm, dim3(l.out), dim3(256), 0, s, tr.dout, ld, Mpad, grads + r.b_off);
         if ((rc = bucket_done())) return rc;
         G2 d{};
+        d.bf16 = tr.bf16;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = tr.dout; d.lda = ld; d.B = l.w32; d.ldb = l.in_pad;
         d.C = tr.dact[0]; d.c_rs = l.in_pad; d.c_cs = 1;
@@ -689,6 +727,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         TrainLayerRef& r = ref_of(&l);
         const float* dy = tr.dact[cur];  // [Mpad][out_pad], already masked by this layer's ReLU
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = dy; g.lda = l.out_pad; g.B = tr.act[i]; g.ldb = l.in_pad;
         g.c_rs = l.in_pad; g.c_cs = 1;
@@ -696,6 +735,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
         if ((rc = bucket_done())) return rc;
         G2 d{};
+        d.bf16 = tr.bf16;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
         d.C = tr.dact[cur ^ 1]; d.c_rs = l.in_pad; d.c_cs = 1;
@@ -708,6 +748,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         TrainLayerRef& r = ref_of(&l);
         const float* dy = tr.dact[cur];  // [Mpad][proj.out_pad]
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
         g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
         g.c_rs = l.in_pad; g.c_cs = 1;
@@ -727,11 +768,13 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         MlpLayer &l2 = c->temb2, &l0 = c->temb0;
         TrainLayerRef &r2 = ref_of(&l2), &r0 = ref_of(&l0);
         G2 g{};
+        g.bf16 = tr.bf16;
         g.M = tp; g.N = tp; g.K = tr.Tpad; g.kchunk = kchunk_for(tr.Tpad, (tp / TM) * (tp / TN));
         g.A = tr.demb; g.lda = tp; g.B = tr.e1_tab; g.ldb = tp; g.c_rs = tp; g.c_cs = 1;
         // the bias gradients (column sums of demb / dtab) ride in the GEMMs as the row sums of their transposed A operand
         if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r2.w_off, grads + r2.b_off))) return rc;
         G2 d{};
+        d.bf16 = tr.bf16;
         d.M = tr.Tpad; d.N = tp; d.K = tp; d.kchunk = tp;
         d.A = tr.demb; d.lda = tp; d.B = l2.w32; d.ldb = tp; d.C = tr.dtab; d.c_rs = tp; d.c_cs = 1;
         if ((rc = launch<false, true>(d, s))) return rc;
@@ -786,6 +829,13 @@ extern "C" int mtk_train_set_bucket_events(mtk_ctx* c, int n, void* const* event
         }
         tr.bucket_events[i] = (hipEvent_t)events[i];
     }
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_precision(mtk_ctx* c, int precision) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_precision: null context");
+    if (precision != MTK_PREC_FP32 && precision != MTK_PREC_BF16) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_set_precision: %d (fp32 or bf16)", precision);
+    c->train.bf16 = precision == MTK_PREC_BF16 ? 1 : 0;
     return MTK_OK;
 }
 

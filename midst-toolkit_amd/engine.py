@@ -254,6 +254,13 @@ class Engine:
         check(_lib.lib().mtk_train_set_bucket_events(self._h, len(events), handles))
         self._bucket_events = list(events)
 
+    def train_set_precision(self, precision: str) -> None:
+        """"fp32" (default, the parity path) or "bf16": bf16 operands / fp32 accumulation in every GEMM of the iteration, fp32
+        master weights and optimizer (mtk_train_set_precision)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"training precision {precision!r}: fp32 or bf16")
+        check(_lib.lib().mtk_train_set_precision(self._h, PRECISIONS[precision]))
+
     def train_set_deterministic(self, on: bool) -> None:
         """True (default): fixed-order reductions, gradients bit-identical run to run; False: fp32 hardware atomics."""
         check(_lib.lib().mtk_train_set_deterministic(self._h, int(bool(on))))

@@ -100,6 +100,65 @@ def test_gradients_match_autograd(tag, B, layers):
         assert num <= 2e-4 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
 
 
+@pytest.mark.parametrize("B,layers", [(4096, [512] * 4), (2048, [1024] * 4), (1000, [256, 128, 256])])
+def test_bf16_training_gradients(B, layers):
+    """mtk_train_set_precision(MTK_PREC_BF16): every GEMM of the iteration multiplies bf16-rounded operands with fp32 accumulation
+    (fp32 master weights, gradients and optimizer).  Stated tolerance, against the oracle's fp32 autograd: losses within 2e-3,
+    every gradient tensor within 3e-2 relative L2 (measured 8e-3 at 4x512, 1.8e-2 at 4x1024: the roundings chain through the layers), and still bit
+    identical run to run."""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=layers)
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    x0, t, eps, u = big_batch(c, B)
+    s = orc.make_schedule(c["T"], "cosine")
+    want, lm_ref, lg_ref = orc.loss_and_grads(s, c["K"], c["Nn"], p0, x0, t, eps, u)
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    eng.train_set_precision("bf16")
+    lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+    args = (x0.to(dev()), t.to(dev()), eps.to(dev()), u.to(dev()), 1.0 / B, lm, lg)
+    eng.train_step(*args)
+    got = export(tr, "grads")
+    first = tr.state[1].clone()
+    assert abs(float(lg.mean()) - float(lg_ref)) <= 2e-3 * abs(float(lg_ref)) and abs(float(lm.mean()) - float(lm_ref)) <= 2e-3 * abs(float(lm_ref))
+    worst = 0.0
+    for k in want:
+        num, den = float((got[k].double() - want[k].double()).norm()), float(want[k].double().norm())
+        worst = max(worst, num / max(den, 1e-30))
+        assert num <= 3e-2 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+    print(f"bf16 training gradients, {layers} x {B}: worst relative L2 error {worst:.3e}")
+    eng.train_step(*args)
+    assert torch.equal(tr.state[1], first)
+    eng.train_set_precision("fp32")
+    eng.train_step(*args)
+    got32 = export(tr, "grads")
+    for k in want:
+        assert float((got32[k].double() - want[k].double()).norm()) <= 2e-4 * float(want[k].double().norm()) + 1e-9
+
+
+def test_bf16_training_berka_run():
+    """The 200-step Berka run of test_berka_run_200_steps with the bf16 training GEMMs.  Stated tolerance on the loss curve against
+    the fp32 reference curve: the first 10 losses within 5e-3, mean deviation <= 4e-2 and max <= 2e-1 over the 200 steps (measured
+    2.2e-2 / 1.0e-1; the run's own chaos floor under a 1e-7 perturbation is 6.4e-3 / 3.3e-2), the last 20 losses' mean within 3 %
+    (measured 1.1 %)."""
+    from tests.test_oracle_train import load_berka
+
+    c = load_berka()
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    tr, d = build_trainer(c, p0, float(c["lr"]), float(c["wd"]), c["steps"])
+    tr._engine.train_set_precision("bf16")
+    hist = []
+    for step, (x0, t, eps, u) in enumerate(c["batches"]):
+        lm, lg = tr._train_step(x0, None, injected=(t.to(dev()), eps.to(dev()), None))
+        tr._anneal_learning_rate(step)
+        hist.append(float(lg))
+    hist, ref = np.asarray(hist), c["losses"][:, 1]
+    rel = np.abs(hist - ref) / np.abs(ref)
+    print(f"berka 200-step curve, bf16 training: max rel deviation {rel.max():.3e}, mean {rel.mean():.3e}, first 10 {rel[:10].max():.3e}; "
+          f"last-20 mean {hist[-20:].mean():.4f} vs {ref[-20:].mean():.4f}")
+    assert rel[:10].max() <= 5e-3 and rel.mean() <= 4e-2 and rel.max() <= 2e-1, (rel[:10].max(), rel.mean(), rel.max())
+    assert abs(hist[-20:].mean() - ref[-20:].mean()) <= 3e-2 * ref[-20:].mean()
+
+
 @pytest.mark.parametrize("B,layers", [(4096, [512] * 4), (1000, [256, 128, 256])])
 def test_gradients_are_bit_identical_run_to_run(B, layers):
     """The reference pipeline runs with torch.use_deterministic_algorithms (common/random.py:11-55).  Default mode here:
