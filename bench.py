@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--sample-rows", type=int, default=65536)
+    ap.add_argument("--sample-rows", type=int, default=262144)
     a = ap.parse_args()
 
     if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr
@@ -401,7 +401,7 @@ def main():
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--sample-rows", type=int, default=65536)
+    ap.add_argument("--sample-rows", type=int, default=262144)
     a = ap.parse_args()
 
     if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr

@@ -147,6 +147,11 @@ class ClavaDDPMTrainer:
         self.ema_model._synced_key = None
         torch.cuda.synchronize(self.device)
 
+    def set_train_precision(self, precision: str) -> None:
+        """Not in the reference (it trains in fp32): "bf16" runs the iteration's GEMMs on bf16 MFMA with fp32 accumulation, fp32
+        master weights / AdamW / EMA (mtk_train_set_precision; tolerances in tests/test_gpu_train.py); "fp32" is the parity path."""
+        self._engine.train_set_precision(precision)
+
     def finish(self) -> None:
         """Detach the training state: the denoiser is re-packed (fp32 + bf16 images) on its next use."""
         self.sync_modules()
