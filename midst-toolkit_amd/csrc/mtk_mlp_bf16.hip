@@ -87,26 +87,25 @@ __device__ __forceinline__ void static_for(F&& f) {
 // than issued as a burst that would drain the matrix pipe).
 template <int EXP>  // EXP: compile-time ablation switches of the diagnostic (stamp) builds; 0 in the product kernels
 struct Pipe {
-    const unsigned char* src;  // wfrag + lane * 16
+    const unsigned char* src;  // wfrag (wave-uniform: lives in SGPRs)
     int total_chunks;
     int next;                  // chunk of the stream being requested
     unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer being filled
     int lane, wid;
     static constexpr int kExp = EXP;  // 1 = no weight DMA after the prologue, 2 = no chunk barrier, 4 = no layer epilogues
 
-    // piece K (0..7) of the chunk being requested: fragment wid + 4 K; 64 lanes x 16 B, dest = base + lane * 16
+    // piece K (0..7) of the chunk being requested: fragment wid + 4 K; 64 lanes x 16 B, dest = base + lane * 16.
+    // Scalar base + per-lane 32-bit offset (no 64-bit VALU address), and M0 is written but neither saved nor restored:
+    // the compiler keeps nothing in M0 in this kernel (no LDS-direct, GWS or message instruction; checked in the ISA),
+    // and the two extra s_mov per piece were 424 x 2 issue slots per tile.
     template <int K>
     __device__ __forceinline__ void piece() {
         if constexpr (!(EXP & 1)) {
             const int f = wid + 4 * K;
             const unsigned dst = __builtin_amdgcn_readfirstlane(dma + (unsigned)f * kFragBytes);
             const unsigned char* gp = src + (size_t)next * kChunkBytes + (size_t)f * kFragBytes;
-            unsigned keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(gp), "s"(dst)
-                : "memory");
+            const unsigned voff = (unsigned)lane * 16u;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(gp) : "memory");
         }
         if constexpr (K == 7) {
             next = (next + 1 == total_chunks) ? 0 : next + 1;
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     }
 
-    Pipe<EXP> p{a.wfrag + (size_t)lane * 16, a.total_chunks, 0, 0u, 0u, lane, wid};
+    Pipe<EXP> p{a.wfrag, a.total_chunks, 0, 0u, 0u, lane, wid};
     p.fetch_all();  // chunk 0 -> buffer 0
     p.fetch_all();  // chunk 1 -> buffer 1
     p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
