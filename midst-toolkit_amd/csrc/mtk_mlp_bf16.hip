@@ -508,9 +508,11 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         // ---- input fragments: bf16 of x (MODE 0) or of x_t = a x + b noise_p (MODE 1, GMD:302 / TF:86)
         bf16x8 XI[KS0];
         if constexpr (MODE == 0) {
-            // the record and its emb[t] + bias rows are loaded HERE, not a tile ahead: at this point the activation
-            // registers of the previous tile are dead, so the 8 KS0 + 64 values in flight cost no spills; only the
-            // timestep (one register) is requested a tile ahead.  One exposed global round trip per 128-row tile.
+            // the record and its emb[t] + bias rows are loaded HERE, not a tile ahead: only the timestep (one register) is
+            // requested a tile ahead.  One exposed global round trip per 128-row tile (≈7 k of a tile's 85 k cycles at
+            // D = 120).  Requesting them before the previous tile's head instead was built and measured: the round trip
+            // left the prologue, and the same cycles reappeared in the hidden layers and the head (128 more live registers
+            // changed their allocation; the compiler's vmcnt wait for them drains the weight DMA either way) - no gain.
             request_x(cur);
             request_emb(t_cur);
             static_for<KS0>([&](auto ic) {
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int f = 32 * nt + 8 * (r >> 2) + 4 * hq + (r & 3);
-                        if (f < Dq) orow[(int64_t)f * ocs] = o[r];
+                        // only the last tile can reach past D = the number of outputs (DT = ceil(D / 32))
+                        if (nt < DT - 1 || f < Dq) orow[(int64_t)f * ocs] = o[r];
                     }
                 }
             } else {
@@ -712,11 +715,12 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     const size_t lds = lds_need(L, a);
     if (lds > kMaxLds) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused kernel: %zu bytes of LDS needed, %zu available", lds, kMaxLds);
     static const bool stamps_env = getenv("MTK_FUSED_STAMPS") != nullptr;
-    if (stamps_env && L.DT == 1 && a.mode == 1) {
+    if (stamps_env && ((L.DT == 1 && a.mode == 1) || (L.DT == 4 && a.mode == 0))) {
         static unsigned long long* d_st = nullptr;
         using Kern = void (*)(FusedArgs);
-        static const Kern kerns[4] = {k_fused<512, 1, 1, true, 0>, k_fused<512, 1, 1, true, 1>, k_fused<512, 1, 1, true, 2>, k_fused<512, 1, 1, true, 4>};
-        const Kern kern = kerns[a.exp == 1 ? 1 : a.exp == 2 ? 2 : a.exp == 4 ? 3 : 0];
+        static const Kern kerns[5] = {k_fused<512, 1, 1, true, 0>, k_fused<512, 1, 1, true, 1>, k_fused<512, 1, 1, true, 2>, k_fused<512, 1, 1, true, 4>,
+                                      k_fused<512, 4, 0, true, 0>};  // the last: forward mode, shape M (sampling, mixed_loss)
+        const Kern kern = a.mode == 0 ? kerns[4] : kerns[a.exp == 1 ? 1 : a.exp == 2 ? 2 : a.exp == 4 ? 3 : 0];
         if (!d_st) {
             MTK_HIP(hipMalloc(&d_st, 64));
             for (Kern k : kerns) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
