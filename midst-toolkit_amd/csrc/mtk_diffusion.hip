@@ -1286,9 +1286,12 @@ int max_levels(const mtk_ctx* c) {  // widest categorical block of the table
     for (int32_t k : c->K) m = k > m ? k : m;
     return m;
 }
-int grid_for(int64_t B) {
+// cap = 2048: 256 CUs x 8 resident workgroups, grid-stride covers the rest.  The record-staging variants of q_sample / loss_rows
+// (no per-workgroup copy of the schedule) take 16384: one pass per workgroup up to 4 M rows, the dispatcher balances the tail
+// (measured at 2^20 rows: q_sample -3 %, loss_rows -7 %; p_sample_step +3 % slower, so it keeps 2048).
+int grid_for(int64_t B, int cap = 2048) {
     int64_t g = (B + kBlock - 1) / kBlock;
-    if (g > 2048) g = 2048;  // 256 CUs x 8 resident workgroups; grid-stride covers the rest
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -1339,7 +1342,7 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
     // replaces the LDS copy of the schedule rows, which then come from L2: measured equal)
     const bool stage = ctx->fast_math && x0_ld <= kStageLd && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && !getenv("MTK_NO_STAGE");
     if (stage) {
-        hipLaunchKernelGGL((k_q_sample_fast<false, true>), dim3(grid_for(B)), dim3(kBlock),
+        hipLaunchKernelGGL((k_q_sample_fast<false, true>), dim3(grid_for(B, 16384)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
         return mtk_poison_bad_t(t, B, ctx->T, x_in, xi_rs, xi_cs, ctx->D, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
@@ -1365,7 +1368,7 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     const bool small = max_levels(ctx) <= kKCacheSmall;
     if (stage) {  // as in mtk_q_sample
         auto ks = small ? k_loss_rows_fast_small<false, true> : k_loss_rows_fast<false, true>;
-        hipLaunchKernelGGL(ks, dim3(grid_for(B)), dim3(kBlock),
+        hipLaunchKernelGGL(ks, dim3(grid_for(B, 16384)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
         return mtk_poison_bad_t(t, B, ctx->T, loss_multi, 1, 0, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);  // the MSE term does not depend on t
