@@ -280,6 +280,11 @@ int mtk_train_set_deterministic(mtk_ctx* ctx, int on);
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the master weights, the gradient image, AdamW and EMA stay fp32.
  * MTK_PREC_FP32 (default) is the parity path.  Stated tolerance: tests/test_gpu_train.py. */
 int mtk_train_set_precision(mtk_ctx* ctx, int precision);
+/* Which Gaussian loss the training iteration evaluates and differentiates: 0 = MSE (GMD:506-532, default), 1 = the KL / decoder-NLL
+ * term of the variational bound in bits per dimension (GaussianLossType.KL: GMD:431-484, 534-541; DU:9-91).  loss_gauss then holds
+ * that term per record (fp32 here; mtk_gauss_kl_rows gives it in fp64) and the backward differentiates it, the clamp at 1e-12 and
+ * the three bins of the discretised likelihood included. */
+int mtk_train_set_gaussian_loss(mtk_ctx* ctx, int kl);
 /* No reference counterpart (the reference trains on one device; north_star part 1 / SURVEY 2c "bucketed per layer, overlapped"):
  * data-parallel overlap of the gradient exchange with the backward.  The gradient image falls into buckets in the order the
  * backward completes them - head, hidden layers last to first, proj, time-embedding MLP.  mtk_train_bucket_layout returns their

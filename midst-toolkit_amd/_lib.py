@@ -57,6 +57,7 @@ _SIGS = {
     "mtk_train_step": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, C.c_double, _p, _p, _u64, _u64, _p]),
     "mtk_train_bucket_layout": (C.c_int, [_p, _i32, _p, _p]),
     "mtk_train_set_bucket_events": (C.c_int, [_p, _i32, _p]),
+    "mtk_train_set_gaussian_loss": (C.c_int, [_p, _i32]),
     "mtk_train_set_precision": (C.c_int, [_p, _i32]),
     "mtk_train_set_deterministic": (C.c_int, [_p, _i32]),
     "mtk_train_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),

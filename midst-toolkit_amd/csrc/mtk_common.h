@@ -93,6 +93,7 @@ struct mtk_ctx {
     SchedRow* d_rows = nullptr;
     int32_t* d_off = nullptr;
     float* d_logK = nullptr;
+    bool train_gauss_kl = false;  // mtk_train_set_gaussian_loss
     double* d_kl = nullptr;  // [T][4]: posterior_mean_coef1/2, posterior_log_variance_clipped, model log-variance (KL Gaussian loss; built on first use)
     const uint64_t* seed_src = nullptr;  // device {seed, row0} read by the reverse-chain kernels instead of their arguments (graph replay)
     int64_t reserved_rows = 0;           // mtk_ctx_reserve: workspaces stay sized for calls of up to this many rows
@@ -140,6 +141,7 @@ struct mtk_ctx {
 // for addressing (mtk_tclamp) and the entry point then overwrites the outputs of rows whose timestep was outside
 // [0, T) with NaN (mtk_poison_bad_t, mtk_diffusion.hip): an out-of-range timestep is loud, never an out-of-bounds read.
 // The reference's sinusoid embedding accepts any t; here the embedding is a [T] table.
+int mtk_ensure_kl_tab(mtk_ctx* ctx);
 int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0, int64_t cs0, int n0, float* p1, int64_t rs1,
                      int64_t cs1, int n1, double* p2, hipStream_t s);
 

@@ -1078,7 +1078,19 @@ struct LossGradArgs {
     float* dout;
     float gscale, mscale;  // 2 / (Nn B_global),  T / (C B_global)
     uint64_t seed, row0;
+    // Gaussian loss = the KL / decoder-NLL term of the variational bound (GaussianLossType.KL, GMD:431-484) instead of the MSE:
+    // kl_tab = the [T][4] coefficient table of k_gauss_kl_rows (null: MSE), kscale = w_gauss / (Nn ln 2)
+    const double* kl_tab;
+    float kscale;
 };
+// derivative of DU:48-59's tanh approximation of the standard normal CDF
+__device__ __forceinline__ double approx_normal_cdf_grad(double v) {
+    const double k = 0.79788456080286535588, th = tanh(k * (v + 0.044715 * (v * v * v)));
+    return 0.5 * k * (1.0 + 3.0 * 0.044715 * (v * v)) * (1.0 - th * th);
+}
+__device__ __forceinline__ double approx_normal_cdf_fwd(double v) {
+    return 0.5 * (1.0 + tanh(0.79788456080286535588 * (v + 0.044715 * (v * v * v))));
+}
 
 template <bool FAST> __device__ __forceinline__ float ex(float x) { return FAST ? __expf(x) : expf(x); }
 template <bool FAST> __device__ __forceinline__ float lg(float x) { return FAST ? __logf(x) : logf(x); }
@@ -1109,15 +1121,50 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
             float* go = a.dout + row;
             PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
             PhiloxNF pf(a.seed, a.row0 + row, MTK_STREAM_EPS);
-            for (int j = w; j < Nn; j += kLgWaves) {
-                const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
-                const float df = mo[j * a.ld] - e;
-                accg += df * df;
-                go[j * a.ld] = a.gscale * df;
-            }
             const SchedRow st = s.rows[t];
             const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
             const float* xr = a.x0 + row * a.x0_ld;
+            if (!a.kl_tab) {
+                for (int j = w; j < Nn; j += kLgWaves) {
+                    const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
+                    const float df = mo[j * a.ld] - e;
+                    accg += df * df;
+                    go[j * a.ld] = a.gscale * df;
+                }
+            } else {
+                // _vb_terms_bpd (GMD:431-484) and its derivative with respect to the predicted noise: the model mean is
+                // c1 (sr x_t - srm1 eps_hat) + c2 x_t, so d mean / d eps_hat = -c1 srm1 for every feature
+                const double* tb = a.kl_tab + (size_t)t * 4;
+                const float c1 = (float)tb[0], c2 = (float)tb[1];
+                const double lv1 = (double)(float)tb[2], lv2 = tb[3];
+                const double e2 = exp(-lv2), half_head = 0.5 * (((-1.0 + lv2) - lv1) + exp(lv1 - lv2)), inv_stdv = exp(-(0.5 * lv2));
+                const float slope = c1 * st.sqrt_recipm1_acp;  // = -d mean / d eps_hat
+                for (int j = w; j < Nn; j += kLgWaves) {
+                    const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
+                    const float xs = xr[j];
+                    const float xj = st.sqrt_acp * xs + st.sqrt_1m_acp * e;   // GMD:302, as k_q_sample forms it
+                    const float x0_hat = st.sqrt_recip_acp * xj - st.sqrt_recipm1_acp * mo[j * a.ld];
+                    const float mean = c1 * x0_hat + c2 * xj;
+                    double term, grad;
+                    if (t != 0) {
+                        const float d = (c1 * xs + c2 * xj) - mean;
+                        term = half_head + 0.5 * ((double)(d * d) * e2);
+                        grad = (double)d * e2 * (double)slope;
+                    } else {
+                        const float centered = xs - mean;
+                        const double up = inv_stdv * (double)(centered + (float)(1.0 / 255.0)), um = inv_stdv * (double)(centered - (float)(1.0 / 255.0));
+                        const double cp = approx_normal_cdf_fwd(up), cm = approx_normal_cdf_fwd(um);
+                        double pr, dpr;  // probability of the bin and its derivative with respect to `centered`
+                        if (xs < -0.999f) { pr = cp; dpr = approx_normal_cdf_grad(up) * inv_stdv; }
+                        else if (xs > 0.999f) { pr = 1.0 - cm; dpr = -approx_normal_cdf_grad(um) * inv_stdv; }
+                        else { pr = cp - cm; dpr = (approx_normal_cdf_grad(up) - approx_normal_cdf_grad(um)) * inv_stdv; }
+                        term = -log(fmax(pr, 1e-12));
+                        grad = pr > 1e-12 ? -(dpr / pr) * (double)slope : 0.0;  // clamp(min = 1e-12) passes no gradient below it
+                    }
+                    accg += (float)term;
+                    go[j * a.ld] = a.kscale * (float)grad;
+                }
+            }
             for (int k = w; k < C; k += kLgWaves) {
                 const int o = s.off[k], Kk = s.off[k + 1] - o;
                 const float logK = s.logK[k];
@@ -1191,7 +1238,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
             float g = 0.0f, m = 0.0f;
 #pragma unroll
             for (int i = 0; i < kLgWaves; ++i) { g += part_g[i][lane]; m += part_m[i][lane]; }
-            if (a.loss_gauss && Nn > 0) a.loss_gauss[row] = g / (float)Nn;
+            if (a.loss_gauss && Nn > 0) a.loss_gauss[row] = a.kl_tab ? (g / (float)Nn) * 1.44269504088896340736f : g / (float)Nn;
             if (a.loss_multi && C > 0) a.loss_multi[row] = m / (float)C;
         }
         __syncthreads();
@@ -1312,6 +1359,21 @@ int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0,
     return MTK_OK;
 }
 
+// per-timestep coefficients of the KL Gaussian loss, built on first use (synchronous copy)
+int mtk_ensure_kl_tab(mtk_ctx* ctx) {
+    if (ctx->d_kl) return MTK_OK;
+    std::vector<double> h((size_t)ctx->T * 4);
+    for (int i = 0; i < ctx->T; ++i) {
+        h[(size_t)i * 4 + 0] = ctx->tab(MTK_TAB_POST_COEF1, i);
+        h[(size_t)i * 4 + 1] = ctx->tab(MTK_TAB_POST_COEF2, i);
+        h[(size_t)i * 4 + 2] = ctx->tab(MTK_TAB_POST_LOGVAR_CLIPPED, i);
+        h[(size_t)i * 4 + 3] = ctx->tab(MTK_TAB_MODEL_LOGVAR64, i);
+    }
+    MTK_HIP(hipMalloc(&ctx->d_kl, h.size() * sizeof(double)));
+    MTK_HIP(hipMemcpy(ctx->d_kl, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MTK_OK;
+}
+
 // internal (mtk_train.hip): per-record losses and d(mean loss)/d(out); out / dout column-major [D][ld]
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
@@ -1319,7 +1381,13 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
     // d(w_gauss * sum_rows loss_gauss + w_multi * sum_rows loss_multi) / d out
     LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
                    ctx->Nn > 0 ? (float)(2.0 * w_gauss / ctx->Nn) : 0.0f,
-                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0};
+                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0, nullptr, 0.0f};
+    if (ctx->train_gauss_kl && ctx->Nn > 0) {
+        const int rc = mtk_ensure_kl_tab(ctx);
+        if (rc) return rc;
+        a.kl_tab = ctx->d_kl;
+        a.kscale = (float)(w_gauss / ((double)ctx->Nn * 0.69314718055994530942));
+    }
     int64_t grid = (B + 63) / 64;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(ctx->fast_math ? k_loss_grad<true> : k_loss_grad<false>, dim3((unsigned)grid), dim3(64 * kLgWaves), lds_bytes(ctx, false), stream, a);
@@ -1504,16 +1572,9 @@ extern "C" int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out
     if (!model_out || !x0 || !x_t || !t || !loss) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: null pointer");
     if (x0_ld < ctx->Nn) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: x0_ld too small");
     MTK_HIP(hipSetDevice(ctx->device));
-    if (!ctx->d_kl) {  // per-timestep coefficients of this loss, built on first use
-        std::vector<double> h((size_t)ctx->T * 4);
-        for (int i = 0; i < ctx->T; ++i) {
-            h[(size_t)i * 4 + 0] = ctx->tab(MTK_TAB_POST_COEF1, i);
-            h[(size_t)i * 4 + 1] = ctx->tab(MTK_TAB_POST_COEF2, i);
-            h[(size_t)i * 4 + 2] = ctx->tab(MTK_TAB_POST_LOGVAR_CLIPPED, i);
-            h[(size_t)i * 4 + 3] = ctx->tab(MTK_TAB_MODEL_LOGVAR64, i);
-        }
-        MTK_HIP(hipMalloc(&ctx->d_kl, h.size() * sizeof(double)));
-        MTK_HIP(hipMemcpy(ctx->d_kl, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        const int rck = mtk_ensure_kl_tab(ctx);
+        if (rck) return rck;
     }
     KlArgs a{B, ctx->Nn, ctx->T, ctx->d_rows, ctx->d_kl, model_out, mo_rs, mo_cs, x0, x0_ld, x_t, xt_rs, xt_cs, t, loss};
     hipLaunchKernelGGL(k_gauss_kl_rows, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, a);
@@ -1543,5 +1604,12 @@ extern "C" int mtk_ctx_set_math(mtk_ctx* ctx, int mode) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_set_math: null context");
     if (mode != MTK_MATH_REFERENCE && mode != MTK_MATH_FAST) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_ctx_set_math: unknown mode %d", mode);
     ctx->fast_math = (mode == MTK_MATH_FAST);
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_gaussian_loss(mtk_ctx* ctx, int kl) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_gaussian_loss: null context");
+    if (kl != 0 && kl != 1) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_set_gaussian_loss: %d (0 = MSE, 1 = KL)", kl);
+    ctx->train_gauss_kl = kl != 0;
     return MTK_OK;
 }

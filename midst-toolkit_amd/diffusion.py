@@ -310,8 +310,6 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         One differentiable forward is outstanding per model at a time (its activations live on the device context)."""
         if not features.is_cuda:
             raise RuntimeError("mixed_loss: midst_toolkit_amd has no CPU path; move the model and batch to the MI355X")
-        if getattr(self.gaussian_loss_type, "value", "mse") != "mse":
-            raise NotImplementedError("the HIP backward pass differentiates the MSE Gaussian loss only (every shipped config)")
         x0 = features.float().contiguous()
         B, dev = x0.shape[0], x0.device
         seed = 0
@@ -327,6 +325,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         net = self._denoise_fn
         eng = self._autograd_engine()
         eng.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
+        eng.train_set_gaussian_loss(getattr(self.gaussian_loss_type, "value", "mse"))  # GMD:534: MSE or the variational-bound term
         params = [p for wb in net._weights() for p in wb]
         lm, lg = _MixedLossFunction.apply(self, x0, t, eps, u, seed, *params)
         zero = torch.zeros((1,)).float().mean()  # GMD:1047-1048, 1068: an absent side is the mean of a CPU zeros((1,)), 0-dim

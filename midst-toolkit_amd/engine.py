@@ -261,6 +261,13 @@ class Engine:
             raise ValueError(f"training precision {precision!r}: fp32 or bf16")
         check(_lib.lib().mtk_train_set_precision(self._h, PRECISIONS[precision]))
 
+    def train_set_gaussian_loss(self, kind: str) -> None:
+        """"mse" (GMD:506-532) or "kl" (the variational-bound term, GMD:431-484, 534-541): which Gaussian loss the training
+        iteration (mtk_train_step / mtk_train_forward / mtk_train_backward) evaluates and differentiates."""
+        if kind not in ("mse", "kl"):
+            raise ValueError(f"Gaussian loss {kind!r}: mse or kl")
+        check(_lib.lib().mtk_train_set_gaussian_loss(self._h, int(kind == "kl")))
+
     def train_set_deterministic(self, on: bool) -> None:
         """True (default): fixed-order reductions, gradients bit-identical run to run; False: fp32 hardware atomics."""
         check(_lib.lib().mtk_train_set_deterministic(self._h, int(bool(on))))

@@ -166,20 +166,28 @@ class Model(nn.Module):
         return self.loss_fn(self.preconditioner, x, _injected).mean(-1).mean()
 
 
+def _karras_sigmas(net: Preconditioner, num_steps: int, device: torch.device) -> Tensor:
+    """The noise levels of utils.py:37-45: num_steps points between sigma_max and sigma_min, uniform in sigma^(1/rho), then 0."""
+    hi, lo = min(SIGMA_MAX, net.sigma_max) ** (1 / rho), max(SIGMA_MIN, net.sigma_min) ** (1 / rho)
+    ramp = torch.arange(num_steps, dtype=torch.float32, device=device) / (num_steps - 1)
+    return torch.cat([(hi + ramp * (lo - hi)) ** rho, torch.zeros(1, dtype=torch.float32, device=device)])
+
+
 def sample_step(net: Preconditioner, num_steps: int, i: int, t_cur: Tensor, t_next: Tensor, x_next: Tensor, _noise: Tensor | None = None) -> Tensor:
-    """utils.py:56-87: one Euler step with the 2nd-order (Heun) correction; both denoiser calls are library calls."""
-    x_cur = x_next
-    gamma = min(S_churn / num_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
-    t_hat = t_cur + gamma * t_cur
-    x_hat = x_cur + (t_hat**2 - t_cur**2).sqrt() * S_noise * (torch.randn_like(x_cur) if _noise is None else _noise)
-    denoised = net(x_hat, t_hat).to(torch.float32)
-    d_cur = (x_hat - denoised) / t_hat
-    x_next = x_hat + (t_next - t_hat) * d_cur
-    if i < num_steps - 1:
-        denoised = net(x_next, t_next).to(torch.float32)
-        d_prime = (x_next - denoised) / t_next
-        x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
-    return x_next
+    """utils.py:56-87, one step of the stochastic Euler-Heun sampler: churn the state up to sigma_hat, take the Euler step
+    along d = (x - D(x, sigma)) / sigma, and (all but the last step) average it with the slope at the arrival point.  Both
+    denoiser evaluations are library calls (mtk_edm_denoise); the state updates are a few element-wise ops on [N, dim]."""
+    churn = min(S_churn / num_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
+    sigma_hat = t_cur + churn * t_cur
+    eps = torch.randn_like(x_next) if _noise is None else _noise
+    x_hat = x_next + (sigma_hat**2 - t_cur**2).sqrt() * S_noise * eps
+    step = t_next - sigma_hat
+    slope = (x_hat - net(x_hat, sigma_hat).to(torch.float32)) / sigma_hat
+    x_euler = x_hat + step * slope
+    if i >= num_steps - 1:
+        return x_euler
+    slope_next = (x_euler - net(x_euler, t_next).to(torch.float32)) / t_next
+    return x_hat + step * (0.5 * slope + 0.5 * slope_next)
 
 
 def sample(net: Preconditioner, num_samples: int, dim: int, num_steps: int = 50, device: torch.device | None = None,
@@ -187,13 +195,9 @@ def sample(net: Preconditioner, num_samples: int, dim: int, num_steps: int = 50,
     """utils.py:20-53.  ``_injected``: {"latents": [N, dim], "noise": [num_steps x [N, dim]]} (tests)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     latents = torch.randn([num_samples, dim], device=device) if _injected is None else _injected["latents"].to(device)
-    step_indices = torch.arange(num_steps, dtype=torch.float32, device=latents.device)
-    sigma_min = max(SIGMA_MIN, net.sigma_min)
-    sigma_max = min(SIGMA_MAX, net.sigma_max)
-    t_steps = (sigma_max ** (1 / rho) + step_indices / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
-    t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])
-    x_next = latents.to(torch.float32) * t_steps[0]
+    sigmas = _karras_sigmas(net, num_steps, latents.device)
+    x = latents.to(torch.float32) * sigmas[0]
     with torch.no_grad():
-        for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
-            x_next = sample_step(net, num_steps, i, t_cur, t_next, x_next, None if _injected is None else _injected["noise"][i].to(device))
-    return x_next
+        for i in range(num_steps):
+            x = sample_step(net, num_steps, i, sigmas[i], sigmas[i + 1], x, None if _injected is None else _injected["noise"][i].to(device))
+    return x

@@ -55,13 +55,11 @@ class ClavaDDPMTrainer:
         self.seed = 0  # base seed of the in-kernel noise when diffusion_model.rng == "philox"
 
         net = diffusion_model._denoise_fn
-        if getattr(diffusion_model.gaussian_loss_type, "value", "mse") != "mse":
-            raise ValueError("the HIP training iteration differentiates the MSE Gaussian loss only (every shipped config); "
-                             f"got {diffusion_model.gaussian_loss_type}")
         if getattr(net, "precision", "fp32") != "fp32" or diffusion_model.precision != "fp32":
             raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
         self._engine = diffusion_model.engine()
         self.state = self._engine.train_attach(timestep_frequencies(net.timestep_dimension))
+        self._engine.train_set_gaussian_loss(getattr(diffusion_model.gaussian_loss_type, "value", "mse"))  # GMD:534
         self._rank, self._world = world()
         # data parallel: one all-reduce per gradient bucket, issued under the backward (distributed.BucketedGradientExchange)
         self._exchange = BucketedGradientExchange(self._engine, self.state[1]) if self._world > 1 else None

@@ -325,11 +325,14 @@ def init_mlp_params(D: int, d_layers: list[int], dim_t: int = 128, seed: int = 0
     return p
 
 
-def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u):
-    """a14 / GMD:1013 with injected (t, eps, u): returns per-record rows and the two means."""
+def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse"):
+    """a14 / GMD:1013 with injected (t, eps, u): returns per-record rows and the two means.  ``gaussian_loss = "kl"``:
+    GaussianLossType.KL (GMD:534-541), the fp64 variational-bound term instead of the MSE."""
     x_num_t, xt_idx = q_sample_fused(s, K, Nn, x0, t, eps, u)
     out = mlp_forward(params, model_input(x_num_t, xt_idx, K), t)
     lm, lg = loss_rows(s, K, Nn, out, x0, xt_idx, eps, t)
+    if gaussian_loss == "kl" and Nn > 0:
+        lg = gaussian_kl_rows(s, out[:, :Nn], x0[:, :Nn], x_num_t, t)
     return lm, lg, lm.mean(), lg.mean()
 
 
@@ -518,12 +521,12 @@ def multinomial_loss_floor(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0:
 
 
 # --------------------------------------------------------------------------- training (a19)
-def loss_and_grads(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], x0, t, eps, u):
+def loss_and_grads(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], x0, t, eps, u, gaussian_loss: str = "mse"):
     """TRAINER:88-91: ``zero_grad; loss_multi + loss_gauss; backward`` with injected (t, eps, u).
     Returns (grads by parameter name, loss_multi mean, loss_gauss mean).  The gradient is torch
     autograd through the restated forward ops, i.e. exactly what the reference differentiates."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u)
+    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u, gaussian_loss)
     (m_mean + g_mean).backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     return grads, m_mean.detach(), g_mean.detach()

@@ -28,6 +28,11 @@ def dev():
     return torch.device("cuda:0")
 
 
+def close(got, want, rtol, atol):
+    got, want = got.double().cpu(), want.double().cpu()
+    assert bool(((got - want).abs() <= rtol * want.abs() + atol).all()), float(((got - want).abs() / (want.abs() + atol)).max())
+
+
 def build_trainer(c, params, lr=2e-3, wd=1e-4, steps=12):
     import midst_toolkit_amd as mtk
 
@@ -98,6 +103,59 @@ def test_gradients_match_autograd(tag, B, layers):
         num = float((got[k].double() - want[k].double()).norm())
         den = float(want[k].double().norm())
         assert num <= 2e-4 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+
+
+@pytest.mark.parametrize("tag", ["B_ragged", "A_numeric"])
+def test_kl_gaussian_loss_gradients(tag):
+    """GaussianLossType.KL in the training iteration (mtk_train_set_gaussian_loss; GMD:431-484, 534-541): per-record bits/dim and the
+    gradient of their batch mean through the decoder NLL (t = 0, all three bins of the discretised likelihood) and the KL branch,
+    against the oracle's autograd through its fp64 restatement of _vb_terms_bpd (which is bit-exact against the reference's KL
+    fixtures).  Also through the autograd seam: mixed_loss(...).backward() on a KL-configured drop-in."""
+    import midst_toolkit_amd as mtk
+
+    c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[128, 128]) if tag == "B_ragged" else dict(K=[0], Nn=8, T=100, D=8, d_layers=[64, 64])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    B = 768
+    x0, t, eps, u = big_batch(c, B)
+    t[:200] = 0                       # plenty of decoder-NLL rows ...
+    x0[:40, 0] = -1.5                 # ... in the lower open bin,
+    x0[40:80, 1] = 1.5                # the upper open bin,
+    x0[80:200, : c["Nn"]] *= 0.3      # and the interior
+    has_cat = c["K"][0] != 0
+    s = orc.make_schedule(c["T"], "cosine")
+    want, lm_ref, lg_ref = orc.loss_and_grads(s, c["K"], c["Nn"], p0, x0, t, eps, u, gaussian_loss="kl")
+    # conditioning: at small t the bound's 1 / variance factor (up to ~1e5 at T = 1000) multiplies an fp32 difference of O(1)
+    # numbers, so the REFERENCE's own gradient moves by ~2e-3 relative under a 1e-7 perturbation of the weights (T = 1000;
+    # ~1e-6 at T = 100).  The bar is 3e-4 + 3 x that movement, measured here per tensor.
+    g7 = torch.Generator().manual_seed(0)
+    p1 = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=g7))).float() for k, v in p0.items()}
+    moved, _, _ = orc.loss_and_grads(s, c["K"], c["Nn"], p1, x0, t, eps, u, gaussian_loss="kl")
+    floor = {k: float((moved[k].double() - want[k].double()).norm()) for k in want}
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    eng.train_set_gaussian_loss("kl")
+    lm = torch.empty(B, device=dev()) if has_cat else None
+    lg = torch.empty(B, device=dev())
+    eng.train_step(x0.to(dev()), t.to(dev()), eps.to(dev()), u.to(dev()) if has_cat else None, 1.0 / B, lm, lg)
+    got = export(tr, "grads")
+    rows = orc.mixed_loss(s, c["K"], c["Nn"], p0, x0, t, eps, u, gaussian_loss="kl")[1]
+    close(lg, rows.float(), rtol=2e-4, atol=1e-5)
+    assert abs(float(lg.mean()) - float(lg_ref)) <= 1e-4 * abs(float(lg_ref))
+    for k in want:
+        num, den = float((got[k].double() - want[k].double()).norm()), float(want[k].double().norm())
+        assert num <= 3e-4 * den + 3 * floor[k] + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e} (floor {floor[k] / max(den, 1e-30):.3e})"
+    # the autograd seam on a KL-configured drop-in
+    net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(c["d_layers"]), 0.0))
+    net.load_state_dict(p0, strict=True)
+    dk = mtk.GaussianMultinomialDiffusion(np.asarray(c["K"]), c["Nn"], net, num_timesteps=c["T"], gaussian_loss_type=mtk.GaussianLossType.KL,
+                                          device=dev()).to(dev())
+    dk._draw_loss_noise = lambda f: (t.to(dev()), eps.to(dev()), u.to(dev()) if has_cat else None)
+    l_m, l_g = dk.mixed_loss(x0.to(dev()), {"y": torch.zeros(B, dtype=torch.long, device=dev())})
+    (l_m + l_g).backward()
+    assert abs(float(l_g) - float(lg_ref)) <= 1e-4 * abs(float(lg_ref))
+    for k, v in dk._denoise_fn.named_parameters():
+        num, den = float((v.grad.cpu().double() - want[k].double()).norm()), float(want[k].double().norm())
+        assert num <= 3e-4 * den + 3 * floor[k] + 1e-9, f"autograd {k}: relative L2 error {num / max(den, 1e-30):.3e}"
 
 
 @pytest.mark.parametrize("B,layers", [(4096, [512] * 4), (2048, [1024] * 4), (1000, [256, 128, 256])])
