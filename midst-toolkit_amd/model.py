@@ -107,8 +107,9 @@ class MLPDiffusion(nn.Module):
         self.input_dimension = input_dimension
         if getattr(is_target_conditioned, "value", is_target_conditioned) == "embedding":
             raise ValueError("is_target_conditioned=EMBEDDING is not on the MI355X path (dead in every reference pipeline)")
-        if diffusion_parameters.dropout != 0.0:
-            raise ValueError("dropout > 0 is not supported by the MI355X denoiser (every reference config uses 0.0)")
+        # dropout > 0 (MODEL:162-180): the Dropout modules are kept for state-dict / structure compatibility and are the identity
+        # in eval mode, which is how scoring and sampling run; with the module in training mode the HIP path refuses (see
+        # _check_dropout): it has no dropout mask, and every reference config trains with 0.0
         self.mlp = MLP.make_baseline(
             input_dimension=timestep_dimension,
             layers_dimensions=self.diffusion_parameters.layers_dimensions,
@@ -158,8 +159,14 @@ class MLPDiffusion(nn.Module):
         self.sync_weights()
         return self._engine
 
+    def _check_dropout(self) -> None:
+        if self.training and float(self.diffusion_parameters.dropout) != 0.0:
+            raise NotImplementedError("MLPDiffusion with dropout > 0 in training mode: the MI355X path evaluates the eval-mode network "
+                                      "(Dropout = identity); call .eval() for scoring / sampling, train such a model with the reference")
+
     def sync_weights(self) -> None:
         """Re-pack the weights into the library when any parameter changed (optimizer step, load)."""
+        self._check_dropout()
         key = tuple((p.data_ptr(), p._version) for wb in self._weights() for p in wb)
         if key != self._synced_key:
             self._engine.set_weights(self._weights(), self._dims(), timestep_frequencies(self.timestep_dimension))

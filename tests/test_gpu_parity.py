@@ -479,6 +479,23 @@ def test_tabsyn_edm_denoiser():
         assert out.shape == (513, 40) and not bool(out.isnan().any())
 
 
+def test_dropout_configured_denoiser_runs_in_eval_mode():
+    """MODEL:162-180: a denoiser configured with dropout > 0 loads and, in eval mode (Dropout = identity: how scoring and sampling
+    call it), gives the dropout-free network's outputs; in training mode the HIP path refuses instead of silently dropping nothing."""
+    import midst_toolkit_amd as mtk
+
+    c = load_case("A_numeric")
+    net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.CONCAT, mtk.DiffusionParameters(list(c["d_layers"]), 0.1))
+    net.load_state_dict(case_params(c), strict=True)
+    d = mtk.GaussianMultinomialDiffusion(c["K"], c["Nn"], net, num_timesteps=c["T"], device=dev()).to(dev())
+    x, t = tt(c["ml_model_in"]).to(dev()), tt(c["ml_t"]).to(dev())
+    with pytest.raises(NotImplementedError):
+        d.engine()
+    d.eval()
+    with torch.no_grad():
+        close(net(x, t), tt(c["ml_model_out"]))
+
+
 def test_conditional_sample_rejects_categorical_tables():
     c = load_case("B_ragged")
     d = build(c, T=4)
