@@ -37,10 +37,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1 << 20)
     ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--levels", type=int, default=10, help="levels per categorical block (SURVEY section 8's stress variant: 100 -> S = 1000, D = 1020)")
     ap.add_argument("--hbm-only", action="store_true", help="only the three HBM-bound diffusion kernels, fast math (PMC passes)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    B, Nn, K, T = a.rows, 20, np.array([10] * 10), 1000
+    B, Nn, K, T = a.rows, 20, np.array([a.levels] * 10), 1000
     C, S = len(K), int(K.sum())
     D = Nn + S
     torch.manual_seed(0)
@@ -72,7 +73,7 @@ def main():
       emit(f"mtk_loss_rows ({tag})", timeit(lambda: eng.loss_rows(out, (1, B), x0, idx, None, t, lm, lg, seed=1)), b_l)
       # reverse step: z fp64 rw + eps_hat + out_cat + idx rw + next model input
       z = torch.randn((Nn, B), device=dev, dtype=torch.float64)
-      zi = torch.randint(0, 10, (C, B), device=dev, dtype=torch.int32)
+      zi = torch.randint(0, a.levels, (C, B), device=dev, dtype=torch.int32)
       b_s = Nn * 8 * 2 + Nn * 4 + S * 4 + C * 4 * 2 + D * 4
       emit(f"mtk_p_sample_step ({tag})", timeit(lambda: eng.p_sample_step(B, 500, False, out, (1, B), z, zi, None, None, x_in, (1, B), seed=1)), b_s)
     eng.set_math("fast")
