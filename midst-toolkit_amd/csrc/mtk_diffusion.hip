@@ -660,10 +660,25 @@ struct BlockExp {
                 sum += e[i];
             }
         } else {
-            for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * cs]);
-            for (int i = 0; i < Kk; ++i) sum += __expf(mc[i * cs] - mx);
+            // streamed block (wider than the register cache): chunks of KC columns whose loads are in flight together,
+            // running max and rescaled running sum - one pass over the block instead of a max pass and a sum pass of
+            // one dependent load each (blocks of 100 levels: loss_rows 0.93 -> TB/s figures in DESIGN section 3)
+            for (int i0 = 0; i0 < Kk; i0 += KC) {
+                float v[KC];
+#pragma unroll
+                for (int i = 0; i < KC; ++i) v[i] = (i0 + i < Kk) ? mc[(int64_t)(i0 + i) * cs] : -INFINITY;
+                float cm = mx;
+#pragma unroll
+                for (int i = 0; i < KC; ++i) cm = fmaxf(cm, v[i]);
+                float part = 0.0f;
+#pragma unroll
+                for (int i = 0; i < KC; ++i) part += __expf(v[i] - cm);  // 0 for the padding columns
+                sum = sum * __expf(mx - cm) + part;                      // mx = -inf on the first chunk: 0 * 0
+                mx = cm;
+            }
         }
     }
+    __device__ __forceinline__ float at(int i) const { return CACHED ? 0.0f : __expf(mc[(int64_t)i * cs] - mx); }  // streamed blocks only
     template <class F>
     __device__ __forceinline__ void each(F&& f) const {
         if (CACHED) {
@@ -671,7 +686,14 @@ struct BlockExp {
             for (int i = 0; i < KC; ++i)
                 if (i < Kk) f(i, e[i]);
         } else {
-            for (int i = 0; i < Kk; ++i) f(i, __expf(mc[i * cs] - mx));
+            for (int i0 = 0; i0 < Kk; i0 += KC) {
+                float v[KC];
+#pragma unroll
+                for (int i = 0; i < KC; ++i) v[i] = (i0 + i < Kk) ? mc[(int64_t)(i0 + i) * cs] : -INFINITY;
+#pragma unroll
+                for (int i = 0; i < KC; ++i)
+                    if (i0 + i < Kk) f(i0 + i, __expf(v[i] - mx));
+            }
         }
     }
 };
@@ -1034,7 +1056,11 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                 const BlockExp<decltype(tag)::value, KC> be(raw, mc, a.mo_cs, Kk);
                 const float A = acp1 / be.sum;
                 float total = 0.0f;
-                be.each([&](int i, float e) { total += (A * e + Bc) * ((i == cz) ? Qh : Qc); });
+                if constexpr (decltype(tag)::value) {
+                    be.each([&](int i, float e) { total += (A * e + Bc) * ((i == cz) ? Qh : Qc); });
+                } else {  // streamed block: sum_i (A e_i + Bc) Q_i in closed form (Q_i = Qc except at the current state), no pass
+                    total = A * (Qc * be.sum + (Qh - Qc) * be.at(cz)) + Bc * (Qc * (float)Kk + (Qh - Qc));
+                }
                 const float target = u1 * total;
                 float cum = 0.0f;
                 bool found = false;

@@ -558,6 +558,39 @@ def test_wide_categorical_blocks_stress_shape(math):
     assert float((got.t()[same.to(dev())].cpu() - out[same]).abs().max()) <= BF16_TOL * float(out.abs().max())
 
 
+def test_wide_block_reverse_step_draws_the_posterior():
+    """The fast reverse step on a 100-level block (streamed in chunks, closed-form normaliser, inverse-CDF draw from one Philox
+    word): 400k rows with the same state and logits must draw categories with the frequencies of the reference's posterior
+    (oracle.q_posterior on the same logits), within 5 binomial standard deviations per level."""
+    import midst_toolkit_amd as mtk
+
+    K, Nn, T, B, t = np.asarray([100, 5]), 1, 1000, 400_000, 400
+    D = Nn + int(K.sum())
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([32], 0.0))
+    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev()).to(dev())
+    d.rng, d.math = "philox", "fast"
+    eng = d.engine()
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn((1, int(K.sum())), generator=g) * 2.0
+    cur = torch.tensor([[17, 3]])
+    s = orc.make_schedule(T, "cosine")
+    tv = torch.full((1,), t, dtype=torch.long)
+    logp = orc.q_posterior(s, orc.block_log_softmax(logits, K), orc.log_onehot(cur, K), tv, K)[0]
+    want = torch.exp(logp.double())
+    out = torch.cat([torch.zeros((1, Nn)), logits], 1).t().contiguous().to(dev()).expand(D, B).contiguous()
+    z = torch.zeros((Nn, B), dtype=torch.float64, device=dev())
+    zi = cur.t().contiguous().to(device=dev(), dtype=torch.int32).expand(2, B).contiguous()
+    eng.p_sample_step(B, t, False, out, (1, B), z, zi, None, None, None, (0, 0), seed=12345)
+    off = 0
+    for k, Kk in enumerate(K):
+        freq = torch.bincount(zi[k].cpu().long(), minlength=int(Kk)).double() / B
+        p = want[off:off + int(Kk)]
+        assert abs(float(p.sum()) - 1.0) < 1e-5
+        sd = torch.sqrt(p * (1 - p) / B)
+        assert bool(((freq - p).abs() <= 5 * sd + 1e-6).all()), (k, float(((freq - p).abs() / (5 * sd + 1e-6)).max()))
+        off += int(Kk)
+
+
 def test_conditional_sample_rejects_categorical_tables():
     c = load_case("B_ragged")
     d = build(c, T=4)
