@@ -152,7 +152,7 @@ def test_kl_gaussian_loss_gradients(tag):
     dk._draw_loss_noise = lambda f: (t.to(dev()), eps.to(dev()), u.to(dev()) if has_cat else None)
     l_m, l_g = dk.mixed_loss(x0.to(dev()), {"y": torch.zeros(B, dtype=torch.long, device=dev())})
     (l_m + l_g).backward()
-    assert abs(float(l_g) - float(lg_ref)) <= 1e-4 * abs(float(lg_ref))
+    assert abs(float(l_g.detach()) - float(lg_ref)) <= 1e-4 * abs(float(lg_ref))
     for k, v in dk._denoise_fn.named_parameters():
         num, den = float((v.grad.cpu().double() - want[k].double()).norm()), float(want[k].double().norm())
         assert num <= 3e-4 * den + 3 * floor[k] + 1e-9, f"autograd {k}: relative L2 error {num / max(den, 1e-30):.3e}"
