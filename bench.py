@@ -538,6 +538,10 @@ def main():
     fl = flops_per_eval(Nn, 128, hidden)
     achieved = evals_step * fl / (step_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[a.precision]
+    # MFMA FLOPs the fused kernel actually issues per eval: proj is folded into the first hidden layer (same function)
+    # and every operand is padded to MFMA tiles: (16 tiles x 2 DT + 3 x 16 x 32 + DT x 32) MFMAs of 32x32x16 per 32 records
+    dt_tiles = (Nn + 31) // 32
+    executed = (16 * 2 * dt_tiles + 3 * 16 * 32 + dt_tiles * 32) * 1024 if (fused and a.hidden == 512) else None
     kernel_name = {"bf16": "k_fused<512,1,1>: fused Tartan-Federer kernel (noising + denoiser + MSE), one launch per 64 timesteps" if fused
                    else "layered bf16 MFMA denoiser between noising and MSE kernels (whole step)",
                    "bf16x3": "layered split-bf16 MFMA denoiser (k_gemm_bf16<SPLIT>) between noising and MSE kernels (whole step)",
@@ -559,7 +563,11 @@ def main():
                    "sharding": f"records/{world}", "evals_per_step": (n_global if strong else world * n_local) * nt * P},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "kernel": kernel_name, "flops_per_eval": fl, "kernel_ms": kern_ms, "launches_per_step": launches,
-                     "flops_per_launch": evals_step * fl / launches if fused else evals_step * fl},
+                     "flops_per_launch": evals_step * fl / launches if fused else evals_step * fl,
+                     # `achieved` / `frac` use the ALGORITHMIC FLOPs of the reference's network; the kernel evaluates the same
+                     # function with proj folded into the first hidden layer, so its matrix pipe is busy for this fraction of the peak:
+                     "executed_mfma_flops_per_eval": executed,
+                     "mfma_pipe_frac": (achieved / peak * executed / fl) if executed else None},
     }
 
     extras = {}

@@ -111,6 +111,11 @@ struct mtk_ctx {
     size_t wfrag_bytes = 0;
     float* d_bias_all = nullptr;  // concatenated padded biases for the fused kernel
     float* d_embb = nullptr;      // [T][emb_ld] time-embedding table + proj bias (fused kernel)
+    // Tartan-Federer mode of the fused kernel: proj folded into the first hidden layer (no nonlinearity sits between them):
+    // its own fragment stream (W1 Wp, then the hidden layers and the head) and the table W1 (emb[t] + b_proj) + b1, [T][H]
+    void* d_wfrag_tf = nullptr;
+    float* d_embf = nullptr;
+    int tf_chunks = 0;
     bool fused_ok = false;
     // layered bf16 path (mtk_mlp_bf16_layered.hip): bf16 weight images per layer + activation ping-pong
     std::vector<void*> wb16;    // plain bf16 weight images (shapes the fused kernel does not cover)

@@ -1359,9 +1359,10 @@ int max_levels(const mtk_ctx* c) {  // widest categorical block of the table
     for (int32_t k : c->K) m = k > m ? k : m;
     return m;
 }
-// cap = 2048: 256 CUs x 8 resident workgroups, grid-stride covers the rest.  The record-staging variants of q_sample / loss_rows
-// (no per-workgroup copy of the schedule) take 16384: one pass per workgroup up to 4 M rows, the dispatcher balances the tail
-// (measured at 2^20 rows: q_sample -3 %, loss_rows -7 %; p_sample_step +3 % slower, so it keeps 2048).
+// cap = 2048: 256 CUs x 8 resident workgroups, grid-stride covers the rest.  The record-staging variant of q_sample (no
+// per-workgroup copy of the schedule) takes 16384: one pass per workgroup up to 4 M rows, the dispatcher balances the tail
+// (rocprof average at 2^20 rows: 0.150 -> 0.143 ms).  loss_rows and p_sample_step keep 2048: with one pass per workgroup
+// loss_rows' 8 bytes per record left the L2 as 5 x more write traffic (WRITE_SIZE 10 -> 53 MB) and it ran 3 % slower.
 int grid_for(int64_t B, int cap = 2048) {
     int64_t g = (B + kBlock - 1) / kBlock;
     if (g > cap) g = cap;
@@ -1462,7 +1463,7 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
     const bool small = max_levels(ctx) <= kKCacheSmall;
     if (stage) {  // as in mtk_q_sample
         auto ks = small ? k_loss_rows_fast_small<false, true> : k_loss_rows_fast<false, true>;
-        hipLaunchKernelGGL(ks, dim3(grid_for(B, 16384)), dim3(kBlock),
+        hipLaunchKernelGGL(ks, dim3(grid_for(B)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
         return mtk_poison_bad_t(t, B, ctx->T, loss_multi, 1, 0, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);  // the MSE term does not depend on t

@@ -41,7 +41,7 @@ struct FusedArgs {
     const unsigned char* wfrag;
     const float* bias;
     int n_bias;
-    const float* embb;  // [T][emb_ld] time-embedding table with the proj bias folded in
+    const float* embb;  // [T][emb_ld] time-embedding table with the proj bias folded in (mode 1: the folded [T][H] table, emb_ld = H)
     int emb_ld;
     int n_noise;        // floats of the Tartan-Federer noise table staged in LDS (P * D)
     int n_hidden;
@@ -265,14 +265,20 @@ __device__ __forceinline__ constexpr int epi_first(int ks) {  // first epilogue 
         constexpr int tab[32] = {-1, -1, 0, 1, 2, -1, 3, 4, 5, -1, 6, 7, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
         return tab[ks];
     }
-    return (ks >= 2 && ks <= 5) ? 2 * (ks - 2) : -1;  // KS == 8: two parts per step
+    if (KS == 8) return (ks >= 2 && ks <= 5) ? 2 * (ks - 2) : -1;  // two parts per step
+    return ks * 8 / KS;  // KS = 2, 4, 6 (the folded first layer, D <= 32 KS / 2 inputs): the parts spread over every step
 }
 template <int KS>
-__device__ __forceinline__ constexpr int epi_count(int ks) { return epi_first<KS>(ks) < 0 ? 0 : (KS == 32 ? 1 : 2); }
+__device__ __forceinline__ constexpr int epi_count(int ks) {
+    if (KS == 32) return epi_first<KS>(ks) < 0 ? 0 : 1;
+    if (KS == 8) return epi_first<KS>(ks) < 0 ? 0 : 2;
+    return (ks + 1) * 8 / KS - ks * 8 / KS;
+}
 template <int KS>
 __device__ __forceinline__ constexpr int bias_first(int ks) {  // first 16-byte piece (of 4) of the next tile's bias
     if (KS == 32) return ks == 15 ? 0 : ks == 16 ? 1 : ks == 18 ? 2 : ks == 19 ? 3 : -1;
-    return ks == 6 ? 0 : -1;
+    if (KS == 8) return ks == 6 ? 0 : -1;
+    return ks == KS - 1 ? 0 : -1;  // after the last parts of the previous tile's epilogue
 }
 template <int KS>
 __device__ __forceinline__ constexpr int bias_count(int ks) { return bias_first<KS>(ks) < 0 ? 0 : (KS == 32 ? 1 : 4); }
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     float* snoise = sbias + a.n_bias + H;
     float2* scoef = reinterpret_cast<float2*>(snoise + a.n_noise);
     float* semb = reinterpret_cast<float*>(scoef + kMaxTF);
-    float* sx = semb + kDimT;
+    float* sx = semb + (MODE == 1 ? H : kDimT);  // mode 1 stages the folded [H] row (see the proj fold below)
     for (int i = tid; i < a.n_bias + H; i += 256) sbias[i] = i < a.n_bias ? a.bias[i] : 0.0f;
     if (MODE == 1) {
         for (int i = tid; i < a.n_noise; i += 256) snoise[i] = a.noise[i];
@@ -388,10 +394,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         asm volatile("" : "+v"(l16));
         for (int q = wid; q * 1024 < bytes; q += 4)
             if (q * 1024 + l16 < bytes) dma16(src + q * 1024 + l16, sx_off + q * 1024);
-        if (wid == 3 && lane < kDimT / 4) {
-            const int t = a.t_list[k];
-            dma16(reinterpret_cast<const unsigned char*>(a.embb + (int64_t)t * a.emb_ld) + lane * 16,
-                  (unsigned)(reinterpret_cast<unsigned char*>(semb) - mtk_smem_f));
+        if (wid >= 4 - H / 256) {  // the folded emb row of the tile's timestep: H floats, one 1-KiB piece per wave
+            const int t = a.t_list[k], piece = wid - (4 - H / 256);
+            dma16(reinterpret_cast<const unsigned char*>(a.embb + (int64_t)t * a.emb_ld) + piece * 1024 + lane * 16,
+                  (unsigned)(reinterpret_cast<unsigned char*>(semb) - mtk_smem_f) + piece * 1024);
         }
     };
     stage(blockIdx.x);
@@ -535,25 +541,29 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                     XI[ks][j] = (__bf16)v;
                 }
             });
-            const unsigned eb = lds_base(semb, hh);
-            static_for<kDimT / 32>([&](auto ic) {  // proj accumulators <- emb[t] + proj bias, from the staged row
-                pacc[decltype(ic)::value] = load16_lds(eb, 32 * decltype(ic)::value);
-                PIN();
-            });
         }
         const Where nxt = locate(tile + gridDim.x);
         int t_nxt = 0;
         if constexpr (MODE == 0) t_nxt = request_t(nxt);
         const float* sb = sbias + kDimT;
         stamp(0);  // prologue
+        bf16x8 XP[kDimT / 16];  // proj output (forward mode); not in X: the 128 -> H layer reads all of it for every tile
+        if constexpr (MODE == 1) {
+            // ---- proj folded into the first hidden layer: ReLU((W1 Wp) x + [W1 (emb[t] + b_proj) + b1]).  No nonlinearity sits
+            // ---- between the two layers, the tile's timestep is uniform, so the bracket is one staged row of a [T][H] table and
+            // ---- the layer is D -> H: 16 tiles of 2 DT MFMAs instead of 8 + 128 (same function; one bf16 rounding fewer)
+            acc[0] = load16_lds(lds_base(semb, hh), 0);
+            stamp(1);
+            if (a.n_hidden == 1) stage(tile + gridDim.x);
+            dense_tm<KS0, NTH, NTH * KS0 / kChunkFrags, false, false>(p, w0, w1, XI, Xa, Xb, acc, semb, sb + H, hh);
+        } else {
         // ---- proj (D -> 128): four tiles of 2 DT k-steps, k-step-major, its (short) epilogue exposed
-        bf16x8 XP[kDimT / 16];
         dense<KS0, kDimT / 32, 1, false, 0>(p, w0, w1, XI, XP, pacc, sb, hh);
         acc[0] = load16_lds(lds_base(sb, hh), 0);  // bias of the 128 -> H layer's tile 0; every later one rides in the stream
         stamp(1);  // proj
         // ---- 128 -> H, then the H -> H layers (MODEL:300-301), tile-major (dense_tm)
-        if (a.n_hidden == 1) stage(tile + gridDim.x);
         dense_tm<kDimT / 16, NTH, NTH*(kDimT / 16) / kChunkFrags, false, false>(p, w0, w1, XP, Xa, Xb, acc, sb, sb + H, hh);
+        }
         stamp(2);  // 128 -> H
         for (int l = 1; l < a.n_hidden; ++l) {
             sb += H;
@@ -644,8 +654,29 @@ __global__ void k_pack_frags(unsigned short* dst, const float* W, int out, int i
     }
 }
 
+// proj folded into the first hidden layer (Tartan-Federer mode): Wf[h][d] = sum_k W1[h][k] Wp[k][d] on the zero-padded fp32 images
+__global__ void k_fold_w(float* Wf, int ldf, const float* W1, int ld1, const float* Wp, int ldp, int H, int dim_t, int D) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * ldf; i += gridDim.x * blockDim.x) {
+        const int h = i / ldf, d = i - h * ldf;
+        float acc = 0.0f;
+        if (d < D)
+            for (int k = 0; k < dim_t; ++k) acc += W1[(int64_t)h * ld1 + k] * Wp[(int64_t)k * ldp + d];
+        Wf[i] = acc;
+    }
+}
+// embf[t][h] = sum_k W1[h][k] (emb[t][k] + b_proj[k]) + b1[h]
+__global__ void k_fold_emb(float* embf, const float* W1, int ld1, const float* embb, int emb_ld, const float* b1, int T, int H, int dim_t) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)T * H; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / H), h = (int)(i - (int64_t)t * H);
+        float acc = b1[h];
+        for (int k = 0; k < dim_t; ++k) acc += W1[(int64_t)h * ld1 + k] * embb[(int64_t)t * emb_ld + k];
+        embf[i] = acc;
+    }
+}
+
 struct Layout {
     int H, DT, n_hidden, total_chunks, n_bias;
+    int tf_chunks, tail_chunk0;  // folded stream: its length; first chunk of the unfolded stream it shares (hidden layers, head)
 };
 
 bool layout_for(const mtk_ctx* c, Layout& L) {
@@ -663,6 +694,8 @@ bool layout_for(const mtk_ctx* c, Layout& L) {
     const int c_hh = nth * ksh / kChunkFrags;
     const int c_head = (L.DT * ksh + kChunkFrags - 1) / kChunkFrags;
     L.total_chunks = 1 + c_l1 + (c->n_hidden - 1) * c_hh + c_head;
+    L.tail_chunk0 = 1 + c_l1;
+    L.tf_chunks = nth * 2 * L.DT / kChunkFrags + (c->n_hidden - 1) * c_hh + c_head;  // folded D -> H layer: nth tiles x 2 DT k-steps
     L.n_bias = kDimT + c->n_hidden * H + 32 * L.DT;
     return true;
 }
@@ -693,21 +726,21 @@ int n_cus(int device) {
 
 // bytes of LDS a launch needs: chunk buffers, biases (+H zeros), noise table, (a, b) per timestep, emb row, records
 size_t lds_need(const Layout& L, const FusedArgs& a) {
-    const size_t floats = (size_t)L.n_bias + L.H + a.n_noise + 2 * kMaxTF + kDimT + (a.mode == 1 ? 128 * (size_t)a.x_ld : 0);
+    const size_t floats = (size_t)L.n_bias + L.H + a.n_noise + 2 * kMaxTF + (a.mode == 1 ? L.H : kDimT) + (a.mode == 1 ? 128 * (size_t)a.x_ld : 0);
     return kBufs * kChunkBytes + ((floats * 4 + 15) & ~(size_t)15);
 }
 
 int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     Layout L;
     if (!layout_for(c, L)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused denoiser: unsupported shape");
-    a.wfrag = reinterpret_cast<const unsigned char*>(c->d_wfrag);
+    a.wfrag = reinterpret_cast<const unsigned char*>(a.mode == 1 ? c->d_wfrag_tf : c->d_wfrag);
     a.bias = c->d_bias_all;
     a.n_bias = L.n_bias;
-    a.embb = c->d_embb;
+    a.embb = a.mode == 1 ? c->d_embf : c->d_embb;
     a.n_noise = (a.mode == 1) ? a.P * c->D : 0;
-    a.emb_ld = c->emb_ld;
+    a.emb_ld = a.mode == 1 ? L.H : c->emb_ld;
     a.n_hidden = L.n_hidden;
-    a.total_chunks = L.total_chunks;
+    a.total_chunks = a.mode == 1 ? L.tf_chunks : L.total_chunks;
     a.D = c->D;
     static const int exp_env = getenv("MTK_FUSED_EXP") ? atoi(getenv("MTK_FUSED_EXP")) : 0;
     a.exp = exp_env;
@@ -757,6 +790,11 @@ void mtk_free_fused(mtk_ctx* c) {
     if (c->d_wfrag) (void)hipFree(c->d_wfrag);
     if (c->d_bias_all) (void)hipFree(c->d_bias_all);
     if (c->d_embb) (void)hipFree(c->d_embb);
+    if (c->d_wfrag_tf) (void)hipFree(c->d_wfrag_tf);
+    if (c->d_embf) (void)hipFree(c->d_embf);
+    c->d_wfrag_tf = nullptr;
+    c->d_embf = nullptr;
+    c->tf_chunks = 0;
     if (c->tf_pack) (void)hipFree(c->tf_pack);
     c->tf_pack = nullptr;
     c->tf_pack_elems = 0;
@@ -811,6 +849,25 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
         boff += H;
     }
     pack(c->head, L.DT, ksh, 1, (L.DT * ksh + kChunkFrags - 1) / kChunkFrags);
+    {   // the Tartan-Federer stream: the folded D -> H layer, then the hidden layers and the head as they stand above
+        const int ldf = 32 * L.DT, c_f = nth * 2 * L.DT / kChunkFrags;
+        float* Wf = nullptr;
+        MTK_HIP(hipMalloc(&Wf, sizeof(float) * (size_t)H * ldf));
+        MTK_HIP(hipMalloc(&c->d_wfrag_tf, (size_t)L.tf_chunks * kChunkBytes));
+        MTK_HIP(hipMalloc(&c->d_embf, sizeof(float) * (size_t)c->T * H));
+        hipLaunchKernelGGL(k_fold_w, dim3(64), dim3(256), 0, s, Wf, ldf, c->blocks[0].w32, c->blocks[0].in_pad, c->proj.w32, c->proj.in_pad, H, kDimT, c->D);
+        hipLaunchKernelGGL(k_fold_emb, dim3(1024), dim3(256), 0, s, c->d_embf, c->blocks[0].w32, c->blocks[0].in_pad, c->d_embb, c->emb_ld,
+                           c->blocks[0].b32, c->T, H, kDimT);
+        unsigned short* dtf = reinterpret_cast<unsigned short*>(c->d_wfrag_tf);
+        hipLaunchKernelGGL(k_pack_frags, dim3(512), dim3(256), 0, s, dtf, Wf, H, ldf, nth, 2 * L.DT, 1, (int64_t)0);
+        MTK_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char*>(c->d_wfrag_tf) + (size_t)c_f * kChunkBytes,
+                               reinterpret_cast<const unsigned char*>(c->d_wfrag) + (size_t)L.tail_chunk0 * kChunkBytes,
+                               (size_t)(L.total_chunks - L.tail_chunk0) * kChunkBytes, hipMemcpyDeviceToDevice, s));
+        MTK_HIP(hipGetLastError());
+        MTK_HIP(hipStreamSynchronize(s));
+        (void)hipFree(Wf);
+        c->tf_chunks = L.tf_chunks;
+    }
     MTK_HIP(hipGetLastError());
     MTK_HIP(hipStreamSynchronize(s));
     c->fused_ok = true;
