@@ -799,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
 
 struct TruePost { float lt_c0, lt_ct, w_c0, w_ct, w_cc, w_sum, self; };
 
-template <bool LDS_ROWS, bool STAGE, int KC>
+template <bool LDS_ROWS, bool STAGE, int KC, bool STREAM>
 __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
@@ -927,7 +927,9 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
                     else sum_log_cc += lp;
                 });
             };
-            if (Kk <= KC) model(CachedTag{}); else model(StreamTag{});
+            // STREAM = false: the host picked this instantiation because no block is wider than KC, and the streamed
+            // path is not even compiled (its chunk registers cost the small kernel 11 spilled VGPRs and 3x its stores)
+            if (!STREAM || Kk <= KC) model(CachedTag{}); else model(StreamTag{});
             const float lse_m = flog(total);
             float cross = w_c0 * lp_c0 + w_cc * sum_log_cc;              // sum_i w_i log P_i
             if (!eq) cross += w_ct * lp_ct;
@@ -944,11 +946,11 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
 }
 
 template <bool LDS_ROWS, bool STAGE>
-__global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) { loss_rows_fast_body<LDS_ROWS, STAGE, kKCache>(a); }
+__global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) { loss_rows_fast_body<LDS_ROWS, STAGE, kKCache, true>(a); }
 // no block wider than kKCacheSmall: 96 registers, five waves per SIMD
 template <bool LDS_ROWS, bool STAGE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_loss_rows_fast_small(LossArgs a) {
-    loss_rows_fast_body<LDS_ROWS, STAGE, kKCacheSmall>(a);
+    loss_rows_fast_body<LDS_ROWS, STAGE, kKCacheSmall, false>(a);
 }
 
 template <int KC>
