@@ -818,13 +818,21 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
         const int t = mtk_tclamp(a.t[row], a.d.T);
         const float* mo = a.mo + row * a.mo_rs;
         const bool multi = a.loss_multi && C > 0;
-        // the first categorical block's inputs go out before the Gaussian part is consumed
-        BlockRaw<KC> raw;
-        int c0 = 0, ct = 0;
+        // Categorical blocks are requested TWO blocks ahead of their use (three rotating register images): a lane's chain
+        // of dependent round trips - not the byte rate - bounds this kernel (a wave lives ~35 us per record at five waves
+        // per SIMD, a dozen exposed HBM latencies), so the bytes a wave keeps in flight are what counts.  The first two
+        // blocks' inputs go out before the Gaussian part is consumed.
+        BlockRaw<KC> rb[3];
+        int c0s[3] = {0, 0, 0}, cts[3] = {0, 0, 0};
+        auto fetch = [&](int k, BlockRaw<KC>& dst, int& c0d, int& ctd) {
+            const int o = s.off[k];
+            dst.load(mo + (int64_t)(Nn + o) * a.mo_cs, a.mo_cs, s.off[k + 1] - o);
+            c0d = (int)(long long)xr[Nn + k];
+            ctd = a.xt_idx[(int64_t)k * a.B + row];
+        };
         if (multi) {
-            raw.load(mo + (int64_t)Nn * a.mo_cs, a.mo_cs, s.off[1]);
-            c0 = (int)(long long)xr[Nn];
-            ct = a.xt_idx[row];
+            fetch(0, rb[0], c0s[0], cts[0]);
+            if (C > 1) fetch(1, rb[1], c0s[1], cts[1]);
         }
         if (a.loss_gauss && Nn > 0) {
             PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
@@ -856,17 +864,9 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
         int Kc = -1;
         TruePost tpE{}, tpN{};
         float logK = 0.0f, q_hot = 0.0f, q_cold = 0.0f, e_hot = 0.0f, e_cold = 0.0f, Bc = 0.0f, Qh = 0.0f, Qc = 0.0f, prior_k = 0.0f;
-        for (int k = 0; k < C; ++k) {
+        auto block = [&](int k, const BlockRaw<KC>& raw, int c0, int ct) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
             const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
-            // next block's inputs
-            BlockRaw<KC> nxt;
-            int c0n = 0, ctn = 0;
-            if (k + 1 < C) {
-                nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
-                c0n = (int)(long long)xr[Nn + k + 1];
-                ctn = a.xt_idx[(int64_t)(k + 1) * a.B + row];
-            }
             // constants of (t, K): recomputed only when K changes from one block to the next (K is wave-uniform)
             if (Kk != Kc) {
                 Kc = Kk;
@@ -913,32 +913,49 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
             const float w_cc = eq ? tpE.w_cc : tpN.w_cc;
             const float self = eq ? tpE.self : tpN.self, w_sum = eq ? tpE.w_sum : tpN.w_sum;
             (void)lt_c0; (void)lt_ct;
-            // model posterior in probability space: P_i = (A e_i + Bc) Q_i, log p_i = log P_i - log sum P
-            float total = 0.0f, sum_log_cc = 0.0f, lp_c0 = 0.0f, lp_ct = 0.0f;
+            // model posterior in probability space: P_i = (A e_i + Bc) Q_i, log p_i = log P_i - log sum P.  The kernel is
+            // VALU-bound (SQ counters: 10 k vector instructions per wave, the matrix of per-column logs the largest
+            // part), so the column loop is branch-free and in log2 units: the bare v_log_f32 per column (HIP's __logf is
+            // the twelve-instruction precise expansion), every column summed and the two special ones picked by selects
+            // and subtracted afterwards, one multiplication by ln 2 per block, v_rcp_f32 for the normaliser.
+            float total = 0.0f, l2_all = 0.0f, l2_c0 = 0.0f, l2_ct = 0.0f;
             auto model = [&](auto tag) {
                 const BlockExp<decltype(tag)::value, KC> be(raw, mc, a.mo_cs, Kk);
-                const float A = acp1 / be.sum;
+                const float A = acp1 * __builtin_amdgcn_rcpf(be.sum);
                 be.each([&](int i, float e) {
                     const float P = (A * e + Bc) * ((i == ct) ? Qh : Qc);
                     total += P;
-                    const float lp = flog(P);
-                    if (i == c0) lp_c0 = lp;
-                    else if (i == ct) lp_ct = lp;
-                    else sum_log_cc += lp;
+                    const float l2 = __builtin_amdgcn_logf(P);
+                    l2_all += l2;
+                    l2_c0 = (i == c0) ? l2 : l2_c0;
+                    l2_ct = (i == ct) ? l2 : l2_ct;
                 });
             };
             // STREAM = false: the host picked this instantiation because no block is wider than KC, and the streamed
             // path is not even compiled (its chunk registers cost the small kernel 11 spilled VGPRs and 3x its stores)
             if (!STREAM || Kk <= KC) model(CachedTag{}); else model(StreamTag{});
-            const float lse_m = flog(total);
+            // t = 0 with a vanishing e_c0 (a logit gap beyond 87): v_log_f32 flushes the denormal P to -inf; the
+            // reference's log-softmax stays finite there, this path saturates at 2^-126.  For t > 0, Bc > 0 keeps P normal.
+            l2_c0 = fmaxf(l2_c0, -126.0f);
+            constexpr float kLn2 = 0.69314718055994531f;
+            const float lp_c0 = kLn2 * l2_c0, lp_ct = kLn2 * l2_ct;
+            const float sum_log_cc = kLn2 * (l2_all - l2_c0 - (eq ? 0.0f : l2_ct));
+            const float lse_m = kLn2 * __builtin_amdgcn_logf(total);
             float cross = w_c0 * lp_c0 + w_cc * sum_log_cc;              // sum_i w_i log P_i
             if (!eq) cross += w_ct * lp_ct;
             kl += (self - cross) + lse_m * w_sum;                        // self = sum_i w_i log w_i
             nll += lp_c0 - lse_m;                  // log-probability of x_0 (columns weighted 1e-30 dropped)
             prior += prior_k;
-            raw = nxt;
-            c0 = c0n;
-            ct = ctn;
+        };
+        for (int k0 = 0; k0 < C; k0 += 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int k = k0 + j;
+                if (k < C) {
+                    if (k + 2 < C) fetch(k + 2, rb[(j + 2) % 3], c0s[(j + 2) % 3], cts[(j + 2) % 3]);
+                    block(k, rb[j], c0s[j], cts[j]);
+                }
+            }
         }
         const float lt = (t == 0) ? -nll : kl;
         a.loss_multi[row] = (lt * (float)T + prior) / (float)C;
@@ -947,9 +964,9 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
 
 template <bool LDS_ROWS, bool STAGE>
 __global__ __launch_bounds__(kBlock) void k_loss_rows_fast(LossArgs a) { loss_rows_fast_body<LDS_ROWS, STAGE, kKCache, true>(a); }
-// no block wider than kKCacheSmall: 96 registers, five waves per SIMD
+// no block wider than kKCacheSmall: three 12-column images in flight fit four waves per SIMD (128 registers)
 template <bool LDS_ROWS, bool STAGE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void k_loss_rows_fast_small(LossArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_loss_rows_fast_small(LossArgs a) {
     loss_rows_fast_body<LDS_ROWS, STAGE, kKCacheSmall, false>(a);
 }
 
