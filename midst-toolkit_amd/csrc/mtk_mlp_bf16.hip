@@ -47,7 +47,7 @@ struct FusedArgs {
     int n_hidden;
     int total_chunks;
     int64_t rows;
-    int mode;  // 0: denoiser forward, 1: Tartan-Federer score
+    int mode;  // 0: denoiser forward (per-row timesteps), 1: Tartan-Federer score, 2: denoiser forward at one timestep (sampling)
     int D;
     // mode 0
     const float* x; int64_t x_rs, x_cs;
@@ -349,6 +349,9 @@ __device__ __forceinline__ void dma16(const void* gp, unsigned dst) {
 // MODE 1: Tartan-Federer score.  Tiles never straddle a timestep, so t is tile-uniform: the tile's records
 //         (a contiguous block of x, <= 128 x x_ld floats) and its emb[t] + bias row are brought into LDS by DMA during
 //         the previous tile's last hidden layer — no per-tile global load ever lands in a VGPR.
+// MODE 2: denoiser forward with ONE timestep for the whole launch (every step of the reverse chain): records in and
+//         outputs out as in mode 0, layers as in mode 1 - proj folded into the first hidden layer, whose bias row
+//         (row t of the folded [T][H] table) is copied into LDS once per launch.
 template <int H, int DT, int MODE, bool STAMP = false, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     constexpr int KS0 = 2 * DT;   // input k-steps (D padded to 32 DT)
@@ -362,8 +365,10 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     float* snoise = sbias + a.n_bias + H;
     float2* scoef = reinterpret_cast<float2*>(snoise + a.n_noise);
     float* semb = reinterpret_cast<float*>(scoef + kMaxTF);
-    float* sx = semb + (MODE == 1 ? H : kDimT);  // mode 1 stages the folded [H] row (see the proj fold below)
+    float* sx = semb + (MODE != 0 ? H : kDimT);  // modes 1, 2 hold the folded [H] row (see the proj fold below)
     for (int i = tid; i < a.n_bias + H; i += 256) sbias[i] = i < a.n_bias ? a.bias[i] : 0.0f;
+    if (MODE == 2)
+        for (int i = tid; i < H; i += 256) semb[i] = a.embb[(int64_t)a.t_scalar * a.emb_ld + i];
     if (MODE == 1) {
         for (int i = tid; i < a.n_noise; i += 256) snoise[i] = a.noise[i];
         for (int i = tid; i < kMaxTF; i += 256) {
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     auto locate = [&](int64_t tile) {
         Where w;
         w.kk = 0; w.pp = 0; w.rl = 0; w.xoff = 0;
-        if (MODE == 0) {
+        if (MODE != 1) {
             // the lane's row inside the tile goes through an opaque copy: left visible, its 64-bit image, the address of
             // its timestep and its share of the emb row address are loop invariants that get hoisted and spilled
             int lrow = wid * 32 + li;
@@ -458,9 +463,9 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
     auto request_t = [&](const Where& w) -> int {
         return a.tvec ? (w.valid ? mtk_tclamp(a.tvec[w.row], a.T) : 0) : a.t_scalar;
     };
-    float raw[MODE == 0 ? KS0 * 8 : 1];
+    float raw[MODE != 1 ? KS0 * 8 : 1];
     auto request_x = [&](const Where& w) {
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
             // Branch-free (every load is issued, clamped to a valid address, and masked afterwards) and with the lane
             // half, D and the column stride made opaque per tile: left visible, the 8 KS0 clamped feature indices,
             // their 64-bit offsets and their `f < D` masks are loop invariants that get hoisted out of the tile loop and
@@ -513,14 +518,14 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         stamp(-1);
         // ---- input fragments: bf16 of x (MODE 0) or of x_t = a x + b noise_p (MODE 1, GMD:302 / TF:86)
         bf16x8 XI[KS0];
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
             // the record and its emb[t] + bias rows are loaded HERE, not a tile ahead: only the timestep (one register) is
             // requested a tile ahead.  One exposed global round trip per 128-row tile (≈7 k of a tile's 85 k cycles at
             // D = 120).  Requesting them before the previous tile's head instead was built and measured: the round trip
             // left the prologue, and the same cycles reappeared in the hidden layers and the head (128 more live registers
             // changed their allocation; the compiler's vmcnt wait for them drains the weight DMA either way) - no gain.
             request_x(cur);
-            request_emb(t_cur);
+            if constexpr (MODE == 0) request_emb(t_cur);
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
@@ -548,13 +553,13 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         const float* sb = sbias + kDimT;
         stamp(0);  // prologue
         bf16x8 XP[kDimT / 16];  // proj output (forward mode); not in X: the 128 -> H layer reads all of it for every tile
-        if constexpr (MODE == 1) {
+        if constexpr (MODE != 0) {
             // ---- proj folded into the first hidden layer: ReLU((W1 Wp) x + [W1 (emb[t] + b_proj) + b1]).  No nonlinearity sits
             // ---- between the two layers, the tile's timestep is uniform, so the bracket is one staged row of a [T][H] table and
             // ---- the layer is D -> H: 16 tiles of 2 DT MFMAs instead of 8 + 128 (same function; one bf16 rounding fewer)
             acc[0] = load16_lds(lds_base(semb, hh), 0);
             stamp(1);
-            if (a.n_hidden == 1) stage(tile + gridDim.x);
+            if (MODE == 1 && a.n_hidden == 1) stage(tile + gridDim.x);
             dense_tm<KS0, NTH, NTH * KS0 / kChunkFrags, false, false>(p, w0, w1, XI, Xa, Xb, acc, semb, sb + H, hh);
         } else {
         // ---- proj (D -> 128): four tiles of 2 DT k-steps, k-step-major, its (short) epilogue exposed
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                 if constexpr (nt == 0) epi_at<KSH, ks, NTH - 1>(acc[1], Xb);
             });
             const f32x16 o = acc[hb];
-            if constexpr (MODE == 0) {
+            if constexpr (MODE != 1) {
                 if (cur.valid) {
                     int64_t ocs = a.o_cs;  // opaque for the same reason as in request_x
                     int hq = hh, Dq = a.D;
@@ -726,21 +731,21 @@ int n_cus(int device) {
 
 // bytes of LDS a launch needs: chunk buffers, biases (+H zeros), noise table, (a, b) per timestep, emb row, records
 size_t lds_need(const Layout& L, const FusedArgs& a) {
-    const size_t floats = (size_t)L.n_bias + L.H + a.n_noise + 2 * kMaxTF + (a.mode == 1 ? L.H : kDimT) + (a.mode == 1 ? 128 * (size_t)a.x_ld : 0);
+    const size_t floats = (size_t)L.n_bias + L.H + a.n_noise + 2 * kMaxTF + (a.mode != 0 ? L.H : kDimT) + (a.mode == 1 ? 128 * (size_t)a.x_ld : 0);
     return kBufs * kChunkBytes + ((floats * 4 + 15) & ~(size_t)15);
 }
 
 int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     Layout L;
     if (!layout_for(c, L)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused denoiser: unsupported shape");
-    a.wfrag = reinterpret_cast<const unsigned char*>(a.mode == 1 ? c->d_wfrag_tf : c->d_wfrag);
+    a.wfrag = reinterpret_cast<const unsigned char*>(a.mode != 0 ? c->d_wfrag_tf : c->d_wfrag);
     a.bias = c->d_bias_all;
     a.n_bias = L.n_bias;
-    a.embb = a.mode == 1 ? c->d_embf : c->d_embb;
+    a.embb = a.mode != 0 ? c->d_embf : c->d_embb;
     a.n_noise = (a.mode == 1) ? a.P * c->D : 0;
-    a.emb_ld = a.mode == 1 ? L.H : c->emb_ld;
+    a.emb_ld = a.mode != 0 ? L.H : c->emb_ld;
     a.n_hidden = L.n_hidden;
-    a.total_chunks = a.mode == 1 ? L.tf_chunks : L.total_chunks;
+    a.total_chunks = a.mode != 0 ? L.tf_chunks : L.total_chunks;
     a.D = c->D;
     static const int exp_env = getenv("MTK_FUSED_EXP") ? atoi(getenv("MTK_FUSED_EXP")) : 0;
     a.exp = exp_env;
@@ -750,12 +755,12 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
     const size_t lds = lds_need(L, a);
     if (lds > kMaxLds) MTK_FAIL(MTK_ERR_UNSUPPORTED, "fused kernel: %zu bytes of LDS needed, %zu available", lds, kMaxLds);
     static const bool stamps_env = getenv("MTK_FUSED_STAMPS") != nullptr;
-    if (stamps_env && ((L.DT == 1 && a.mode == 1) || (L.DT == 4 && a.mode == 0))) {
+    if (stamps_env && ((L.DT == 1 && a.mode == 1) || (L.DT == 4 && a.mode != 1))) {
         static unsigned long long* d_st = nullptr;
         using Kern = void (*)(FusedArgs);
-        static const Kern kerns[5] = {k_fused<512, 1, 1, true, 0>, k_fused<512, 1, 1, true, 1>, k_fused<512, 1, 1, true, 2>, k_fused<512, 1, 1, true, 4>,
-                                      k_fused<512, 4, 0, true, 0>};  // the last: forward mode, shape M (sampling, mixed_loss)
-        const Kern kern = a.mode == 0 ? kerns[4] : kerns[a.exp == 1 ? 1 : a.exp == 2 ? 2 : a.exp == 4 ? 3 : 0];
+        static const Kern kerns[6] = {k_fused<512, 1, 1, true, 0>, k_fused<512, 1, 1, true, 1>, k_fused<512, 1, 1, true, 2>, k_fused<512, 1, 1, true, 4>,
+                                      k_fused<512, 4, 0, true, 0>, k_fused<512, 4, 2, true, 0>};  // the last two: forward modes, shape M (mixed_loss; sampling)
+        const Kern kern = a.mode == 0 ? kerns[4] : a.mode == 2 ? kerns[5] : kerns[a.exp == 1 ? 1 : a.exp == 2 ? 2 : a.exp == 4 ? 3 : 0];
         if (!d_st) {
             MTK_HIP(hipMalloc(&d_st, 64));
             for (Kern k : kerns) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
@@ -771,7 +776,7 @@ int run(mtk_ctx* c, FusedArgs& a, hipStream_t s) {
                 h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[7] ? 100.0 * (double)h[6] / (double)h[7] : 0.0);
         return MTK_OK;
     }
-    return a.mode == 1 ? launch<512, 1>(L, a, grid, lds, s) : launch<512, 0>(L, a, grid, lds, s);
+    return a.mode == 1 ? launch<512, 1>(L, a, grid, lds, s) : a.mode == 2 ? launch<512, 2>(L, a, grid, lds, s) : launch<512, 0>(L, a, grid, lds, s);
 }
 
 // [rows][cols] strided -> compact [rows][ld] (zero padded): the fused Tartan-Federer kernel stages records by 16-byte DMA
@@ -819,7 +824,9 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
             reinterpret_cast<const void*>(k_fused<512, 1, 0>), reinterpret_cast<const void*>(k_fused<512, 2, 0>),
             reinterpret_cast<const void*>(k_fused<512, 3, 0>), reinterpret_cast<const void*>(k_fused<512, 4, 0>),
             reinterpret_cast<const void*>(k_fused<512, 1, 1>), reinterpret_cast<const void*>(k_fused<512, 2, 1>),
-            reinterpret_cast<const void*>(k_fused<512, 3, 1>), reinterpret_cast<const void*>(k_fused<512, 4, 1>)};
+            reinterpret_cast<const void*>(k_fused<512, 3, 1>), reinterpret_cast<const void*>(k_fused<512, 4, 1>),
+            reinterpret_cast<const void*>(k_fused<512, 1, 2>), reinterpret_cast<const void*>(k_fused<512, 2, 2>),
+            reinterpret_cast<const void*>(k_fused<512, 3, 2>), reinterpret_cast<const void*>(k_fused<512, 4, 2>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         attr_set = true;
     }
@@ -879,7 +886,7 @@ int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64
                       float* out, int64_t o_rs, int64_t o_cs, hipStream_t s) {
     FusedArgs a{};
     a.rows = B;
-    a.mode = 0;
+    a.mode = t ? 0 : 2;  // one timestep for the launch: the folded first layer (mode 2)
     a.x = x; a.x_rs = x_rs; a.x_cs = x_cs;
     a.tvec = t; a.t_scalar = t_scalar; a.T = c->T;
     a.out = out; a.o_rs = o_rs; a.o_cs = o_cs;
