@@ -1073,20 +1073,33 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
             int arg = Kk - 1;
             auto draw = [&](auto tag) {
                 const BlockExp<decltype(tag)::value, KC> be(raw, mc, a.mo_cs, Kk);
-                const float A = acp1 / be.sum;
-                float total = 0.0f;
+                const float A = acp1 * __builtin_amdgcn_rcpf(be.sum);
+                // inverse CDF: the first column whose running sum exceeds u * total = the number of columns whose running sum
+                // does not (P >= 0, the running sum never falls), capped at the last column - an add, a compare and a counted
+                // carry per column instead of a guarded select
+                int below = 0;
                 if constexpr (decltype(tag)::value) {
-                    be.each([&](int i, float e) { total += (A * e + Bc) * ((i == cz) ? Qh : Qc); });
+                    float Pv[KC], total = 0.0f;  // every P_i once (registers), then the search
+                    be.each([&](int i, float e) {
+                        Pv[i] = (A * e + Bc) * ((i == cz) ? Qh : Qc);
+                        total += Pv[i];
+                    });
+                    const float target = u1 * total;
+                    float cum = 0.0f;
+                    be.each([&](int i, float) {
+                        cum += Pv[i];
+                        below += (cum <= target) ? 1 : 0;
+                    });
                 } else {  // streamed block: sum_i (A e_i + Bc) Q_i in closed form (Q_i = Qc except at the current state), no pass
-                    total = A * (Qc * be.sum + (Qh - Qc) * be.at(cz)) + Bc * (Qc * (float)Kk + (Qh - Qc));
+                    const float total = A * (Qc * be.sum + (Qh - Qc) * be.at(cz)) + Bc * (Qc * (float)Kk + (Qh - Qc));
+                    const float target = u1 * total;
+                    float cum = 0.0f;
+                    be.each([&](int i, float e) {
+                        cum += (A * e + Bc) * ((i == cz) ? Qh : Qc);
+                        below += (cum <= target) ? 1 : 0;
+                    });
                 }
-                const float target = u1 * total;
-                float cum = 0.0f;
-                bool found = false;
-                be.each([&](int i, float e) {
-                    cum += (A * e + Bc) * ((i == cz) ? Qh : Qc);
-                    if (!found && cum > target) { arg = i; found = true; }
-                });
+                arg = below < Kk - 1 ? below : Kk - 1;
             };
             if (Kk <= KC) draw(CachedTag{}); else draw(StreamTag{});
             a.z_idx[(int64_t)k * a.B + row] = arg;
@@ -1380,8 +1393,9 @@ int max_levels(const mtk_ctx* c) {  // widest categorical block of the table
 }
 // cap = 2048: 256 CUs x 8 resident workgroups, grid-stride covers the rest.  The record-staging variant of q_sample (no
 // per-workgroup copy of the schedule) takes 16384: one pass per workgroup up to 4 M rows, the dispatcher balances the tail
-// (rocprof average at 2^20 rows: 0.150 -> 0.143 ms).  loss_rows and p_sample_step keep 2048: with one pass per workgroup
-// loss_rows' 8 bytes per record left the L2 as 5 x more write traffic (WRITE_SIZE 10 -> 53 MB) and it ran 3 % slower.
+// (rocprof average at 2^20 rows: 0.150 -> 0.143 ms).  loss_rows and p_sample_step keep 2048: caps of 1024, 4096 and 16384
+// measured the same within 1 % at 2^20 rows (1280, an uneven 3.2 rows per lane, 12 % slower); neither occupancy, nor the
+// prefetch depth, nor the VALU work moves these kernels off 4.4-4.7 TB/s - 120 column streams 4 MB apart per wave.
 int grid_for(int64_t B, int cap = 2048) {
     int64_t g = (B + kBlock - 1) / kBlock;
     if (g > cap) g = cap;
