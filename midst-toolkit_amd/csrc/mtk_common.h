@@ -121,6 +121,9 @@ struct mtk_ctx {
     std::vector<void*> wb16;    // plain bf16 weight images (shapes the fused kernel does not cover)
     std::vector<void*> wb16x;   // split (hi | lo) bf16 weight images, MTK_PREC_BF16X3 (every shape)
     std::vector<float*> bb16;
+    void* wb16_fold = nullptr;  // bf16 image of W1 Wp (proj folded into the first block; launches with one timestep)
+    float* embf_l = nullptr;    // [T][embf_ld]: W1 (emb[t] + b_proj) + b1, the folded layer's bias row per timestep
+    int embf_ld = 0;
     void* ws16[2] = {nullptr, nullptr};
     size_t ws16_elems = 0;
     int fused_h = 0;

@@ -423,6 +423,29 @@ __global__ void k_to_bf16_split_pad(uint16_t* dst, int rows_pad, int cols_pad, c
         dst[(int64_t)r * 2 * cols_pad + cols_pad + c] = *reinterpret_cast<const uint16_t*>(&l);
     }
 }
+// proj folded into the first block for launches that carry ONE timestep (every step of the reverse chain): no nonlinearity
+// sits between them (MODEL:614, 300), so ReLU(W1 (Wp x + b_proj + emb[t]) + b1) = ReLU((W1 Wp) x + embf[t]) - one GEMM
+// and one activation round trip fewer per pass.  Both products in fp32 on the zero-padded images, rounded to bf16 once.
+__global__ void k_fold_w_l(float* Wf, int ldf, const float* W1, int ld1, const float* Wp, int ldp, int H, int dim_t) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)H * ldf; i += (int64_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i / ldf), d = (int)(i - (int64_t)h * ldf);
+        float acc = 0.0f;
+        for (int k = 0; k < dim_t; ++k) acc += W1[(int64_t)h * ld1 + k] * Wp[(int64_t)k * ldp + d];
+        Wf[i] = acc;
+    }
+}
+__global__ void k_fold_emb_l(float* embf, int ldo, int H, const float* W1, int ld1, const float* emb, int emb_ld, const float* bp, const float* b1,
+                             int T, int dim_t) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)T * ldo; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / ldo), h = (int)(i - (int64_t)t * ldo);
+        float acc = 0.0f;
+        if (h < H) {
+            acc = b1[h];
+            for (int k = 0; k < dim_t; ++k) acc += W1[(int64_t)h * ld1 + k] * (emb[(int64_t)t * emb_ld + k] + bp[k]);
+        }
+        embf[i] = acc;
+    }
+}
 __global__ void k_pad_f32(float* dst, int n_pad, const float* src, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) dst[i] = i < n ? src[i] : 0.0f;
 }
@@ -528,6 +551,11 @@ void mtk_free_layered(mtk_ctx* c) {
     c->wb16x.clear();
     for (float* p : c->bb16) if (p) (void)hipFree(p);
     c->bb16.clear();
+    if (c->wb16_fold) (void)hipFree(c->wb16_fold);
+    if (c->embf_l) (void)hipFree(c->embf_l);
+    c->wb16_fold = nullptr;
+    c->embf_l = nullptr;
+    c->embf_ld = 0;
     for (int i = 0; i < 2; ++i) {
         if (c->ws16[i]) (void)hipFree(c->ws16[i]);
         c->ws16[i] = nullptr;
@@ -559,6 +587,23 @@ int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain) {
         MTK_HIP(hipMalloc(&b, sizeof(float) * (size_t)np));
         c->bb16.push_back(b);
         hipLaunchKernelGGL(k_pad_f32, dim3(8), dim3(256), 0, s, b, np, l->b32, l->out_pad);
+    }
+    if (plain && !c->blocks.empty()) {  // the folded first block (see k_fold_w_l)
+        const MlpLayer& l1 = c->blocks[0];
+        const int kp0 = round_up(c->proj.in_pad, BK), np1 = round_up(l1.out_pad, BT);
+        float* Wf = nullptr;
+        MTK_HIP(hipMalloc(&Wf, sizeof(float) * (size_t)l1.out_pad * c->proj.in_pad));
+        MTK_HIP(hipMalloc(&c->wb16_fold, sizeof(uint16_t) * (size_t)np1 * kp0));
+        MTK_HIP(hipMalloc(&c->embf_l, sizeof(float) * (size_t)c->T * np1));
+        c->embf_ld = np1;
+        hipLaunchKernelGGL(k_fold_w_l, dim3(512), dim3(256), 0, s, Wf, c->proj.in_pad, l1.w32, l1.in_pad, c->proj.w32, c->proj.in_pad, l1.out_pad, c->dim_t);
+        hipLaunchKernelGGL(k_to_bf16_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(c->wb16_fold), np1, kp0, Wf, c->proj.in_pad, l1.out_pad,
+                           c->proj.in_pad);
+        hipLaunchKernelGGL(k_fold_emb_l, dim3(1024), dim3(256), 0, s, c->embf_l, np1, l1.out, l1.w32, l1.in_pad, c->d_emb, c->emb_ld, c->proj.b32, l1.b32,
+                           c->T, c->dim_t);
+        MTK_HIP(hipGetLastError());
+        MTK_HIP(hipStreamSynchronize(s));
+        (void)hipFree(Wf);
     }
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -623,21 +668,28 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         hipLaunchKernelGGL(k_x_to_bf16<SPLIT>, dim3((unsigned)(Mpad / 64), (unsigned)((kp0 + 127) / 128)), dim3(256), 0, s, ws[0], kp0, x + r0 * x_rs, x_rs, x_cs, M, c->D);
         MTK_HIP(hipGetLastError());
         int cur = 0;
-        GemmB g{};
-        g.M = M; g.N = c->proj.out; g.Kpad = kp0;
-        g.X = ws[cur]; g.x_ld = (int64_t)F * kp0; g.x_lo = kp0;
-        g.W = reinterpret_cast<const uint16_t*>(wimg[0]); g.w_ld = (int64_t)F * kp0; g.bias = c->bb16[0];
-        g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar; g.T = c->T;
-        int ld = round_up(c->proj.out_pad, BT);
-        g.Y = ws[cur ^ 1]; g.y_rs = (int64_t)F * ld; g.y_lo = ld;
-        if ((rc = launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s))) return rc;
-        cur ^= 1;
+        // one timestep for the whole launch (plain bf16): proj is folded into the first block, whose bias is row t of embf_l
+        const bool fold = !SPLIT && !t && c->wb16_fold && c->embf_l && t_scalar >= 0 && t_scalar < c->T;
+        int ld = kp0;
+        if (!fold) {
+            GemmB g{};
+            g.M = M; g.N = c->proj.out; g.Kpad = kp0;
+            g.X = ws[cur]; g.x_ld = (int64_t)F * kp0; g.x_lo = kp0;
+            g.W = reinterpret_cast<const uint16_t*>(wimg[0]); g.w_ld = (int64_t)F * kp0; g.bias = c->bb16[0];
+            g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar; g.T = c->T;
+            ld = round_up(c->proj.out_pad, BT);
+            g.Y = ws[cur ^ 1]; g.y_rs = (int64_t)F * ld; g.y_lo = ld;
+            if ((rc = launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s))) return rc;
+            cur ^= 1;
+        }
         for (size_t i = 0; i < c->blocks.size(); ++i) {
             const MlpLayer& l = c->blocks[i];
+            const bool folded = fold && i == 0;
             GemmB h{};
-            h.M = M; h.N = l.out; h.Kpad = round_up(l.in_pad, BK);
+            h.M = M; h.N = l.out; h.Kpad = folded ? kp0 : round_up(l.in_pad, BK);
             h.X = ws[cur]; h.x_ld = (int64_t)F * ld; h.x_lo = ld;
-            h.W = reinterpret_cast<const uint16_t*>(wimg[1 + i]); h.w_ld = (int64_t)F * h.Kpad; h.bias = c->bb16[1 + i]; h.relu = 1;
+            h.W = reinterpret_cast<const uint16_t*>(folded ? c->wb16_fold : wimg[1 + i]); h.w_ld = (int64_t)F * h.Kpad;
+            h.bias = folded ? c->embf_l + (size_t)t_scalar * c->embf_ld : c->bb16[1 + i]; h.relu = 1;
             ld = round_up(l.out_pad, BT);
             h.Y = ws[cur ^ 1]; h.y_rs = (int64_t)F * ld; h.y_lo = ld;
             if ((rc = launch<false, 2, 4, false, SPLIT>(h, c->device, Mpad, ld, s))) return rc;

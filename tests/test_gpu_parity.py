@@ -741,6 +741,39 @@ def test_mlp_forward_bf16_layered(shape):
     assert torch.equal(o2.t().contiguous(), out)
 
 
+@pytest.mark.parametrize("shape", [(20, [512] * 4), (120, [512] * 4), (120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512]), (40, [128, 256])])
+def test_mlp_forward_bf16_one_timestep_launches(shape):
+    """Launches that carry ONE timestep (every step of the reverse chain passes an integer, not a vector) run proj folded
+    into the first hidden layer - the fused kernel's mode 2 and the layered path's folded first block: W1 Wp and
+    W1 (emb[t] + b_proj) + b1 are formed in fp32 and rounded once.  Same function as the per-row path: both within the
+    bf16 bar of the fp32 oracle, and within a few bf16 roundings of each other."""
+    import midst_toolkit_amd as mtk
+
+    D, layers = shape
+    params = orc.init_mlp_params(D, layers, seed=5)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(layers), 0.0)).to(dev())
+    net.load_state_dict(params, strict=True)
+    net.precision = "bf16"
+    eng = net.engine(dev())
+    g = torch.Generator().manual_seed(4)
+    B = 1000
+    x = torch.randn((B, D), generator=g)
+    xd = x.to(dev())
+    for ts in (0, 437, 999):
+        tv = torch.full((B,), ts, dtype=torch.int64)
+        want = orc.mlp_forward(params, x, tv)
+        scale = float(want.abs().max())
+        one = eng.mlp_forward(xd, ts, precision="bf16")
+        per_row = eng.mlp_forward(xd, tv.to(dev()), precision="bf16")
+        assert float((one.cpu() - want).abs().max()) <= BF16_TOL * scale, ts
+        assert float((one - per_row).abs().max()) <= 6e-3 * scale, (ts, float((one - per_row).abs().max()) / scale)
+        # a row's result does not depend on the batch it sits in; column-major in and out
+        assert torch.equal(eng.mlp_forward(xd[130:391].contiguous(), ts, precision="bf16"), one[130:391]), ts
+        o2 = torch.empty((D, B), device=dev())
+        eng.mlp_forward(xd.t().contiguous(), ts, out=o2, precision="bf16", x_strides=(1, B), out_strides=(1, B), B=B)
+        assert torch.equal(o2.t().contiguous(), one), ts
+
+
 @pytest.mark.parametrize("shape", [(120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512])])
 def test_mlp_forward_bf16_layered_many_tiles(shape):
     """The layered GEMM is persistent: a workgroup streams the k-blocks of several output tiles through one LDS double
