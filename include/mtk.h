@@ -108,6 +108,15 @@ int mtk_ctx_reserve(mtk_ctx* ctx, int64_t max_rows, mtk_stream stream);
  * back to the arguments) - a captured chain is replayed with new noise by rewriting 16 bytes. */
 int mtk_ctx_set_seed_source(mtk_ctx* ctx, const uint64_t* seed_row0_dev);
 
+/* MODEL:583-585, 610-612 (IsTargetConditioned.EMBEDDING with num_classes > 0): the denoiser adds
+ * silu(label_embedding.weight[y]) to the time embedding of every record.  Here a (label, timestep) pair is ONE row of the
+ * time-embedding table: create the context with num_timesteps = (n_labels + 1) * period table rows, hand over the raw
+ * [n_labels][dim] fp32 embedding weight (device pointer, copied) BEFORE mtk_mlp_set_weights, and pass row index
+ * (1 + y) * period + t wherever mtk_mlp_forward takes a timestep (rows below `period`: y = None, MODEL:610).  n_labels = 0
+ * clears.  Such a context serves the denoiser forward only: mtk_train_attach refuses, and its schedule tables are not those of
+ * a diffusion object (the Python drop-in keeps a separate context for the diffusion kernels). */
+int mtk_mlp_set_label_embedding(mtk_ctx* ctx, const float* weight_dev, int n_labels, int dim, int period, mtk_stream stream);
+
 /* Replaces MLPDiffusion's parameter storage (MODEL:548-594).  W[i] / b[i] are device pointers to
  * fp32 PyTorch-layout weights [out_i][in_i] / [out_i], in this order:
  *   0 proj, 1 timestep_embedding.0, 2 timestep_embedding.2, 3.. mlp.blocks.*.linear, last mlp.head

@@ -90,5 +90,6 @@ extern "C" void mtk_ctx_destroy(mtk_ctx* c) {
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_logK) (void)hipFree(c->d_logK);
     if (c->d_kl) (void)hipFree(c->d_kl);
+    if (c->d_label) (void)hipFree(c->d_label);
     delete c;
 }

@@ -105,6 +105,8 @@ struct mtk_ctx {
     MlpLayer proj, temb0, temb2, head;
     std::vector<MlpLayer> blocks;
     float* d_emb = nullptr;    // [T][dim_t_pad] time-embedding table
+    float* d_label = nullptr;  // [n_label][dim_t] label-embedding rows (IsTargetConditioned.EMBEDDING, MODEL:610-612); null: none
+    int n_label = 0, t_period = 0, label_dim = 0;  // table row r = (1 + label) * t_period + timestep; rows below t_period carry no label
     int emb_ld = 0;
     // fused bf16 image (mtk_mlp_bf16.hip)
     void* d_wfrag = nullptr;   // packed MFMA A-fragments, consumption order

@@ -157,17 +157,28 @@ __global__ void k_pad_copy(float* dst, int rows_pad, int cols_pad, const float* 
 }
 
 // MODEL:123-144: [cos(t f_i), sin(t f_i)] (+ a zero column when dim is odd), rows padded to BM
-__global__ void k_sinusoid(float* dst, int Tpad, int ld, int T, int dim, const float* freqs) {
+// `period` > 0: row r belongs to timestep r % period (label-conditioned tables, mtk_mlp_set_label_embedding)
+__global__ void k_sinusoid(float* dst, int Tpad, int ld, int T, int dim, const float* freqs, int period) {
     const int half = dim / 2;
     const int64_t n = (int64_t)Tpad * ld;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i / ld), c = (int)(i % ld);
         float v = 0.0f;
         if (t < T && c < 2 * half) {
-            const float arg = (float)t * freqs[c < half ? c : c - half];
+            const float arg = (float)(period > 0 ? t % period : t) * freqs[c < half ? c : c - half];
             v = c < half ? cosf(arg) : sinf(arg);
         }
         dst[i] = v;
+    }
+}
+
+// MODEL:612: embeddings += silu(label_embedding(y)), as rows of the table: row r >= period gets label r / period - 1
+__global__ void k_add_label_rows(float* emb, int ld, int T, int period, const float* label, int dim) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)T * dim; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / dim), c = (int)(i - (int64_t)r * dim);
+        if (r < period) continue;
+        const float v = label[(int64_t)(r / period - 1) * dim + c];
+        emb[(int64_t)r * ld + c] += v / (1.0f + expf(-v));
     }
 }
 
@@ -229,6 +240,35 @@ void mtk_free_mlp(mtk_ctx* c) {
 
 static int reserve_all(mtk_ctx* c, int64_t rows, hipStream_t s);  // below: re-applies an mtk_ctx_reserve reservation
 
+// IsTargetConditioned.EMBEDDING (MODEL:583-585, 610-612).  The denoiser adds silu(label_embedding[y]) to the time embedding;
+// here the pair (label, timestep) is one row of the time-embedding table: the context is created with
+// T = (n_labels + 1) * period table rows, row (1 + y) * period + t carries label y, rows below `period` none (y = None), and
+// the caller passes that row index wherever a timestep goes.  Call before mtk_mlp_set_weights (which builds the table);
+// n_labels = 0 clears.  Contexts with a label table serve the denoiser forward only (no training image).
+extern "C" int mtk_mlp_set_label_embedding(mtk_ctx* c, const float* rows_dev, int n_labels, int dim, int period, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_label_embedding: null context");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    MTK_HIP(hipStreamSynchronize(s));
+    if (c->d_label) (void)hipFree(c->d_label);
+    c->d_label = nullptr;
+    c->n_label = 0;
+    c->t_period = 0;
+    c->label_dim = 0;
+    if (n_labels == 0) return MTK_OK;
+    if (!rows_dev || n_labels < 0 || dim < 2 || period < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_label_embedding: bad argument");
+    if ((int64_t)(n_labels + 1) * period != c->T)
+        MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_label_embedding: the context has %d table rows, (n_labels + 1) * period = %lld", c->T,
+                 (long long)(n_labels + 1) * period);
+    MTK_HIP(hipMalloc(&c->d_label, sizeof(float) * (size_t)n_labels * dim));
+    MTK_HIP(hipMemcpyAsync(c->d_label, rows_dev, sizeof(float) * (size_t)n_labels * dim, hipMemcpyDeviceToDevice, s));
+    MTK_HIP(hipStreamSynchronize(s));
+    c->n_label = n_labels;
+    c->t_period = period;
+    c->label_dim = dim;
+    return MTK_OK;
+}
+
 extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims_host, const float* const* W,
                                    const float* const* b, const float* freqs_host, mtk_stream stream) {
     if (!c || !dims_host || !W || !b || !freqs_host) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: null argument");
@@ -236,6 +276,7 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
     const int D = dims_host[0], dim_t = dims_host[1];
     if (D != c->D) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: denoiser width %d != Nn + S = %d", D, c->D);
     if (dim_t < 2 || dim_t > 1024) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_set_weights: dim_t = %d", dim_t);
+    if (c->d_label && c->label_dim != dim_t) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: label embedding is %d wide, dim_t = %d", c->label_dim, dim_t);
     for (int i = 0; i < n_hidden; ++i)
         if (dims_host[2 + i] < 1 || dims_host[2 + i] > 8192) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_set_weights: hidden[%d] = %d", i, dims_host[2 + i]);
     for (int i = 0; i < n_hidden + 4; ++i)
@@ -271,7 +312,7 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
     MTK_HIP(hipMalloc(&c->d_emb, sizeof(float) * (size_t)Tpad * tpad));
     c->emb_ld = tpad;
     MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (dim_t / 2), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_sinusoid, dim3(256), dim3(256), 0, s, e0, Tpad, tpad, c->T, dim_t, d_freq);
+    hipLaunchKernelGGL(k_sinusoid, dim3(256), dim3(256), 0, s, e0, Tpad, tpad, c->T, dim_t, d_freq, c->d_label ? c->t_period : 0);
     GemmArgs g{};
     g.M = Tpad; g.N = dim_t; g.K = dim_t; g.Kpad = tpad;
     g.X = e0; g.x_rs = tpad; g.W = c->temb0.w32; g.ldw = tpad; g.bias = c->temb0.b32;
@@ -279,6 +320,10 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
     if ((rc = launch_gemm<false, false>(g, Tpad, tpad, s))) return rc;
     g.X = e1; g.W = c->temb2.w32; g.bias = c->temb2.b32; g.act = ACT_NONE; g.Y = c->d_emb;
     if ((rc = launch_gemm<false, false>(g, Tpad, tpad, s))) return rc;
+    if (c->d_label) {
+        hipLaunchKernelGGL(k_add_label_rows, dim3(512), dim3(256), 0, s, c->d_emb, tpad, c->T, c->t_period, c->d_label, dim_t);
+        MTK_HIP(hipGetLastError());
+    }
     MTK_HIP(hipStreamSynchronize(s));
     (void)hipFree(d_freq);
     (void)hipFree(e0);

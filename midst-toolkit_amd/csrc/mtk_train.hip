@@ -522,6 +522,7 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     if (!c || !state || !freqs_host) MTK_FAIL(MTK_ERR_ARG, "mtk_train_attach: null argument");
     if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_train_attach: call mtk_mlp_set_weights first");
     if (c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_attach: a training image is already attached (set the weights again to detach)");
+    if (c->d_label) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_attach: label-conditioned denoisers (mtk_mlp_set_label_embedding) are forward only");
     hipStream_t s = (hipStream_t)stream;
     MTK_HIP(hipSetDevice(c->device));
     MTK_HIP(hipStreamSynchronize(s));

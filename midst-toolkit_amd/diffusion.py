@@ -169,19 +169,33 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         dev = self.alphas.device
         if self._engine is None or self._engine.device != dev:
             self._engine = Engine(dev, self.num_timesteps, self.num_numerical_features, self.num_classes, self._host_tables)
-            if hasattr(self._denoise_fn, "attach_engine"):
+            if getattr(self._denoise_fn, "label_conditioned", False) and getattr(self._denoise_fn, "num_classes", 0) > 0:
+                self._denoise_fn.num_timesteps = self.num_timesteps  # own context: (classes + 1) x T table rows (model.MLPDiffusion.engine)
+            elif hasattr(self._denoise_fn, "attach_engine"):
                 self._denoise_fn.attach_engine(self._engine)
-        if hasattr(self._denoise_fn, "sync_weights"):
+        if self._label_net():
+            self._denoise_fn.engine(dev)
+        elif hasattr(self._denoise_fn, "sync_weights"):
             if getattr(self._engine, "_train_state", None) is not None and self.precision != "fp32" and not getattr(self, "_keep_training_image", False):
                 self._denoise_fn._synced_key = None  # the packed bf16 images do not follow a training image: detach and re-pack
             self._denoise_fn.sync_weights()
         self._engine.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
         return self._engine
 
-    def _denoise_cm(self, eng: Engine, x_in: Tensor, t, B: int, out: Tensor) -> None:
-        """Denoiser on the column-major [D][B] intermediates."""
-        if not hasattr(self._denoise_fn, "sync_weights"):
+    def _label_net(self) -> bool:
+        """IsTargetConditioned.EMBEDDING with classes (MODEL:610-612): the denoiser runs on its own context and takes ``y``."""
+        net = self._denoise_fn
+        return bool(getattr(net, "label_conditioned", False)) and getattr(net, "num_classes", 0) > 0
+
+    def _denoise_cm(self, eng: Engine, x_in: Tensor, t, B: int, out: Tensor, y: Tensor | None = None) -> None:
+        """Denoiser on the column-major [D][B] intermediates (``y``: the labels of a label-conditioned denoiser)."""
+        net = self._denoise_fn
+        if not hasattr(net, "sync_weights"):
             raise TypeError("the MI355X path needs midst_toolkit_amd.MLPDiffusion as denoise_fn")
+        if self._label_net():
+            tv = t if isinstance(t, Tensor) else torch.full((B,), int(t), dtype=torch.int64, device=eng.device)
+            eng = net.engine(eng.device)
+            t = net.table_rows(tv, y)
         eng.mlp_forward(x_in, t, out=out, precision=self.precision, x_strides=(1, B), out_strides=(1, B), B=B)
 
     # ------------------------------------------------------------------ Gaussian pieces used by callers (TF:86-93)
@@ -239,7 +253,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
 
     @torch.no_grad()
     def mixed_loss_rows(self, features: Tensor, timestep: Tensor | None = None, noise: Tensor | None = None,
-                        uniform: Tensor | None = None, seed: int = 0, row0: int = 0):
+                        uniform: Tensor | None = None, seed: int = 0, row0: int = 0, y: Tensor | None = None):
         """Per-record (multinomial / C, gaussian) losses.  With ``timestep``/``noise``/``uniform`` given
         they are injected; otherwise drawn per ``self.rng``.  Returns 1-element zero tensors on CPU
         for an absent side, exactly like GMD:1047-1048."""
@@ -263,7 +277,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
         xt_idx = torch.empty((max(C, 1), B), dtype=torch.int32, device=dev)
         eng.q_sample(x0, t, eps, u, x_in, (1, B), xt_idx, seed, row0)
-        self._denoise_cm(eng, x_in, t, B, out)
+        self._denoise_cm(eng, x_in, t, B, out, y)
         lm = torch.empty((B,), dtype=torch.float32, device=dev) if C > 0 else None
         kl = getattr(self.gaussian_loss_type, "value", "mse") == "kl"  # GMD:534: _vb_terms_bpd instead of the MSE, fp64 like the reference's
         lg = torch.empty((B,), dtype=torch.float64 if kl else torch.float32, device=dev) if Nn > 0 else None
@@ -277,11 +291,14 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return (lm if lm is not None else zero), (lg if lg is not None else zero)
 
     def mixed_loss(self, features: Tensor, outputs: dict[str, Tensor]) -> tuple[Tensor, Tensor]:
-        """GMD:1013: (mean multinomial loss / C, mean Gaussian loss).  ``outputs['y']`` is accepted
-        and ignored like the reference's denoiser ignores it (MODEL:610)."""
+        """GMD:1013: (mean multinomial loss / C, mean Gaussian loss).  ``outputs['y']`` reaches the denoiser only when it is
+        label-conditioned (MODEL:610); every other denoiser ignores it, as the reference's does."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self._label_net():
+                raise NotImplementedError("label-conditioned denoisers (IsTargetConditioned.EMBEDDING) are forward only on the MI355X path: "
+                                          "score / sample under torch.no_grad(), train with the reference")
             return self._mixed_loss_autograd(features)
-        lm, lg = self.mixed_loss_rows(features)
+        lm, lg = self.mixed_loss_rows(features, y=(outputs or {}).get("y") if self._label_net() else None)
         return lm.mean(), lg.mean()
 
     # ------------------------------------------------------------------ differentiable entry point (TRAINER:89-91)
@@ -359,7 +376,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         for k, enum in coerce.items():
             if k in args:
                 args[k] = enum(getattr(args[k], "value", args[k]))
-        net = MLPDiffusion(width, 0, IsTargetConditioned.NONE, DiffusionParameters(layers, 0.0), timestep_dimension=dim_t)
+        lab = sd.get("_denoise_fn.label_embedding.weight")  # IsTargetConditioned.EMBEDDING: [classes, dim_t] (an nn.Linear(1, dim_t) when classes = 0)
+        n_lab = 0 if lab is None or "_denoise_fn.label_embedding.bias" in sd else int(lab.shape[0])
+        net = MLPDiffusion(width, n_lab, IsTargetConditioned.NONE if lab is None else IsTargetConditioned.EMBEDDING,
+                           DiffusionParameters(layers, 0.0), timestep_dimension=dim_t)
         device = torch.device(device) if device is not None else args.pop("device", None) or _default_device()
         args.pop("device", None)
         model = cls(num_classes, nn_, net, device=device, **args)
@@ -400,7 +420,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             z0 = torch.randn((B, Nn), device=dev)
             u0 = draw_u() if C else None
         outputs = draw_outputs()
-        if philox and not ddim and conditioning_function is None and getattr(self, "use_graph", False):
+        y = (outputs or {}).get("y") if self._label_net() else None  # GMD:1406: the denoiser takes **outputs
+        if y is not None:
+            y = y.to(dev)
+        if philox and not ddim and conditioning_function is None and getattr(self, "use_graph", False) and y is None:
             sample = self._replay_chain_graph(eng, B, seed, row0)
             return (sample if getattr(self, "results_on_device", False) else sample.cpu()), outputs
         z = torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev)
@@ -409,7 +432,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
         eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed, row0)
         for i, t in enumerate(reversed(range(T))):
-            self._denoise_cm(eng, x_in, t, B, out)
+            self._denoise_cm(eng, x_in, t, B, out, y)
             n = u = grad = None
             if inj is not None:
                 n = inj["noise"][i] if Nn and not ddim else None
@@ -543,8 +566,9 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         z_idx = torch.empty((1, B), dtype=torch.int32, device=dev)
         x_in = start.to(device=dev, dtype=torch.float32).t().contiguous()
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
+        y = model_kwargs.get("y") if self._label_net() else None  # GMD:1147, 1212: the denoiser takes **outputs
         for i, t in enumerate(steps):
-            self._denoise_cm(eng, x_in, t, B, out)
+            self._denoise_cm(eng, x_in, t, B, out, y.to(dev) if y is not None else None)
             if reverse:
                 eng.ddim_reverse_step(B, t, out, (1, B), z, x_in, (1, B))
                 continue

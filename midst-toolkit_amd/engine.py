@@ -101,6 +101,17 @@ class Engine:
             check(_lib.lib().mtk_mlp_set_weights(self._h, n_hidden, d.ctypes.data, Wp, bp, f.ctypes.data, self._stream()))
         self._train_state = None  # setting weights detaches a training image
 
+    def set_label_embedding(self, weight: torch.Tensor | None, period: int = 0) -> None:
+        """MODEL:610-612 as table rows (mtk_mlp_set_label_embedding): call before set_weights; None clears."""
+        with torch.cuda.device(self.device):
+            if weight is None:
+                check(_lib.lib().mtk_mlp_set_label_embedding(self._h, None, 0, 0, 0, self._stream()))
+                return
+            require_cuda(weight, "set_label_embedding")
+            w = weight.detach().float().contiguous()
+            check(_lib.lib().mtk_mlp_set_label_embedding(self._h, w.data_ptr(), int(w.shape[0]), int(w.shape[1]), int(period), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+
     def mlp_forward(self, x: torch.Tensor, t, out: torch.Tensor | None = None, precision: str = "fp32",
                     x_strides=None, out_strides=None, B: int | None = None) -> torch.Tensor:
         """x: [B, D] fp32 (any strides).  t: int64 [B] tensor or a Python int."""

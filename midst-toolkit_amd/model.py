@@ -105,8 +105,10 @@ class MLPDiffusion(nn.Module):
         self.diffusion_parameters.input_dimension = timestep_dimension
         self.diffusion_parameters.output_dimension = input_dimension
         self.input_dimension = input_dimension
-        if getattr(is_target_conditioned, "value", is_target_conditioned) == "embedding":
-            raise ValueError("is_target_conditioned=EMBEDDING is not on the MI355X path (dead in every reference pipeline)")
+        # MODEL:583-587: the label embedding of IsTargetConditioned.EMBEDDING.  With classes it runs on the MI355X path as extra
+        # rows of the time-embedding table (Engine.set_label_embedding); the regression variant (num_classes == 0, a Linear on
+        # the raw target) is kept for state-dict compatibility and refuses in forward when a target is passed
+        self.label_conditioned = getattr(is_target_conditioned, "value", is_target_conditioned) == "embedding"
         # dropout > 0 (MODEL:162-180): the Dropout modules are kept for state-dict / structure compatibility and are the identity
         # in eval mode, which is how scoring and sampling run; with the module in training mode the HIP path refuses (see
         # _check_dropout): it has no dropout mask, and every reference config trains with 0.0
@@ -116,6 +118,8 @@ class MLPDiffusion(nn.Module):
             dropout=self.diffusion_parameters.dropout,
             output_dimension=input_dimension,
         )
+        if self.label_conditioned:
+            self.label_embedding = nn.Embedding(num_classes, timestep_dimension) if num_classes > 0 else nn.Linear(1, timestep_dimension)
         self.proj = nn.Linear(input_dimension, timestep_dimension)
         self.timestep_embedding = nn.Sequential(
             nn.Linear(timestep_dimension, timestep_dimension),
@@ -143,8 +147,13 @@ class MLPDiffusion(nn.Module):
     def _dims(self):
         return [self.input_dimension, self.timestep_dimension] + [int(b.linear.out_features) for b in self.mlp.blocks]
 
+    def _label_rows(self) -> bool:
+        return self.label_conditioned and self.num_classes > 0
+
     def attach_engine(self, engine: Engine) -> None:
         """Share the diffusion object's context (its D equals this network's width)."""
+        if self._label_rows():
+            raise RuntimeError("a label-conditioned denoiser keeps its own context: its time-embedding table has (classes + 1) x T rows")
         assert engine.D == self.input_dimension, (engine.D, self.input_dimension)
         self._engine, self._engine_shared, self._synced_key = engine, True, None
 
@@ -152,9 +161,10 @@ class MLPDiffusion(nn.Module):
         if self._engine is None or self._engine.device != torch.device(device):
             if self._engine is not None and self._engine_shared:
                 raise RuntimeError("denoiser and diffusion context live on different devices")
-            buf = schedule.buffer_values(schedule.SchedulerType.COSINE, self.num_timesteps)
+            rows = self.num_timesteps * (self.num_classes + 1 if self._label_rows() else 1)  # table rows: (label, timestep) pairs
+            buf = schedule.buffer_values(schedule.SchedulerType.COSINE, rows)
             tabs = {**buf, **schedule.posterior_values(buf)}
-            self._engine = Engine(device, self.num_timesteps, self.input_dimension, [0], tabs)
+            self._engine = Engine(device, rows, self.input_dimension, [0], tabs)
             self._synced_key = None
         self.sync_weights()
         return self._engine
@@ -168,12 +178,19 @@ class MLPDiffusion(nn.Module):
         """Re-pack the weights into the library when any parameter changed (optimizer step, load)."""
         self._check_dropout()
         key = tuple((p.data_ptr(), p._version) for wb in self._weights() for p in wb)
+        if self._label_rows():
+            lw = self.label_embedding.weight
+            key += ((lw.data_ptr(), lw._version, self.num_timesteps),)
         if key != self._synced_key:
+            if self._label_rows():
+                self._engine.set_label_embedding(self.label_embedding.weight, self.num_timesteps)
             self._engine.set_weights(self._weights(), self._dims(), timestep_frequencies(self.timestep_dimension))
             self._synced_key = key
 
     def forward(self, input_tensor: Tensor, timesteps: Tensor, y: Tensor | None = None) -> Tensor:
-        """MODEL:596.  ``y`` is accepted and ignored (is_target_conditioned = NONE on every pipeline)."""
+        """MODEL:596.  ``y`` is ignored unless the network is label-conditioned (IsTargetConditioned.EMBEDDING, MODEL:610-612):
+        then record i runs with table row ``(1 + y[i]) * num_timesteps + timesteps[i]`` (timesteps must be below
+        ``num_timesteps``, the table's period; ``y=None`` takes the label-free rows like the reference)."""
         if not input_tensor.is_cuda:
             raise RuntimeError("MLPDiffusion.forward: midst_toolkit_amd has no CPU path; move the module and inputs to the MI355X")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -183,8 +200,18 @@ class MLPDiffusion(nn.Module):
             )
         eng = self.engine(input_tensor.device)
         x = input_tensor.float()
-        t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        t = self.table_rows(timesteps.to(device=x.device, dtype=torch.int64), y)
         return eng.mlp_forward(x, t, precision=self.precision)
+
+    def table_rows(self, timesteps: Tensor, y: Tensor | None) -> Tensor:
+        """Row of the time-embedding table per record: the timestep, or the (label, timestep) pair of a label-conditioned net."""
+        if self.label_conditioned and y is not None:
+            if self.num_classes == 0:
+                raise NotImplementedError("IsTargetConditioned.EMBEDDING with num_classes == 0 (a Linear on the raw regression target, MODEL:587) "
+                                          "is not on the MI355X path")
+            labels = y.to(device=timesteps.device).long().reshape(-1)  # MODEL:611 squeezes [B, 1] targets
+            timesteps = (labels + 1) * self.num_timesteps + timesteps
+        return timesteps.contiguous()
 
 
 class ModelType(Enum):

@@ -18,6 +18,8 @@ def score_records(diffusion_model: GaussianMultinomialDiffusion, features: Tenso
     """[n_t, B, P] scores: mean_d (noise_p - eps_hat(x_t(record, noise_p, t + add), t))^2."""
     if not features.is_cuda:
         raise RuntimeError("score_records: midst_toolkit_amd has no CPU path; move the records to the MI355X")
+    if diffusion_model._label_net():
+        raise NotImplementedError("Tartan-Federer scoring with a label-conditioned denoiser (IsTargetConditioned.EMBEDDING) is not on the MI355X path")
     eng = diffusion_model.engine()
     x = features[:, : diffusion_model.num_numerical_features].float()
     if x.stride(1) != 1:

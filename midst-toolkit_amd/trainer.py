@@ -55,6 +55,8 @@ class ClavaDDPMTrainer:
         self.seed = 0  # base seed of the in-kernel noise when diffusion_model.rng == "philox"
 
         net = diffusion_model._denoise_fn
+        if getattr(net, "label_conditioned", False):
+            raise NotImplementedError("ClavaDDPMTrainer: label-conditioned denoisers (IsTargetConditioned.EMBEDDING) are forward only on the MI355X path")
         if getattr(net, "precision", "fp32") != "fp32" or diffusion_model.precision != "fp32":
             raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
         self._engine = diffusion_model.engine()

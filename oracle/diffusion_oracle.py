@@ -276,8 +276,9 @@ def time_table(params: dict[str, torch.Tensor], T: int, dim_t: int = 128) -> tor
 
 
 def mlp_forward(params: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, dim_t: int = 128,
-                dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """MODEL:596-615 with ``is_target_conditioned = NONE`` (``y`` ignored), dropout 0.
+                dtype: torch.dtype = torch.float32, y: torch.Tensor | None = None) -> torch.Tensor:
+    """MODEL:596-615, dropout 0.  ``y`` enters only when ``params`` holds ``label_embedding.weight``
+    (IsTargetConditioned.EMBEDDING with classes, MODEL:610-612: embeddings += silu(label_embedding(y.squeeze()))).
     ``dtype=torch.float64`` evaluates the same network in double (used only to measure how far
     the reference's own fp32 result is from the exact value of its formula)."""
     if dtype != torch.float32:
@@ -294,6 +295,8 @@ def mlp_forward(params: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tenso
     e = timestep_embedding(t, dim_t)
     e = F.linear(e, params["timestep_embedding.0.weight"], params["timestep_embedding.0.bias"])
     e = F.linear(F.silu(e), params["timestep_embedding.2.weight"], params["timestep_embedding.2.bias"])
+    if y is not None and "label_embedding.weight" in params:
+        e = e + F.silu(F.embedding(y.long().reshape(-1), params["label_embedding.weight"]))
     h = F.linear(x.float(), params["proj.weight"], params["proj.bias"]) + e
     i = 0
     while f"mlp.blocks.{i}.linear.weight" in params:
@@ -325,11 +328,12 @@ def init_mlp_params(D: int, d_layers: list[int], dim_t: int = 128, seed: int = 0
     return p
 
 
-def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse"):
+def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse", y=None):
     """a14 / GMD:1013 with injected (t, eps, u): returns per-record rows and the two means.  ``gaussian_loss = "kl"``:
-    GaussianLossType.KL (GMD:534-541), the fp64 variational-bound term instead of the MSE."""
+    GaussianLossType.KL (GMD:534-541), the fp64 variational-bound term instead of the MSE.  ``y``: the labels GMD:1042 hands
+    to a label-conditioned denoiser."""
     x_num_t, xt_idx = q_sample_fused(s, K, Nn, x0, t, eps, u)
-    out = mlp_forward(params, model_input(x_num_t, xt_idx, K), t)
+    out = mlp_forward(params, model_input(x_num_t, xt_idx, K), t, y=y)
     lm, lg = loss_rows(s, K, Nn, out, x0, xt_idx, eps, t)
     if gaussian_loss == "kl" and Nn > 0:
         lg = gaussian_kl_rows(s, out[:, :Nn], x0[:, :Nn], x_num_t, t)
@@ -373,8 +377,8 @@ def multinomial_p_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tenso
 
 
 def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us,
-                 mlp_dtype: torch.dtype = torch.float32, conditioning_function=None, model_kwargs=None):
-    """a18 / GMD:1370-1424 with injected randomness.  ``noises[i]``/``us[i]`` belong to the i-th
+                 mlp_dtype: torch.dtype = torch.float32, conditioning_function=None, model_kwargs=None, y=None):
+    """a18 / GMD:1370-1424 with injected randomness (``y``: the drawn labels, GMD:1401, for a label-conditioned denoiser).  ``noises[i]``/``us[i]`` belong to the i-th
     executed step (t = T-1-i).  Returns [B, Nn+C] fp64 (numeric then category codes).
     ``conditioning_function(features, timestep, **model_kwargs)``: classifier guidance (GMD:699-702); with
     K = [0] and u0 = None this is also conditional_sample (GMD:1319-1367), whose state starts the same way."""
@@ -386,7 +390,7 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
         z_idx = gumbel_argmax(torch.zeros((B, int(offsets_of(K)[-1]))), u0, K)
     for i, t in enumerate(reversed(range(s.T))):
         tt = torch.full((B,), t, dtype=torch.long)
-        out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype)
+        out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype, y=y)
         grad = conditioning_function(z, tt, **(model_kwargs or {})) if conditioning_function is not None else None
         z = gaussian_p_step(s, out[:, :Nn], z, t, noises[i], grad)
         if C:

@@ -97,6 +97,18 @@ def load_edm(tag: str = "latent24") -> dict:
     return d
 
 
+def load_label(tag: str = "label3") -> dict:
+    """Fixture of tools/make_golden.py::gen_label_embedding: the reference's label-conditioned denoiser (IsTargetConditioned.EMBEDDING)."""
+    with np.load(os.path.join(GOLDEN, f"label_{tag}.npz")) as z:
+        d = {k: z[k] for k in z.files}
+    for k in ("Nn", "T", "n_labels", "ch_T"):
+        d[k] = int(d[k])
+    d["K"] = np.asarray(d["K"], dtype=np.int64)
+    d["d_layers"] = [int(v) for v in d["d_layers"]]
+    d["params"] = {k[2:]: tt(v) for k, v in d.items() if k.startswith("p_")}
+    return d
+
+
 def load_classifier(tag: str = "A_numeric") -> dict:
     """Fixture of tools/make_golden.py::gen_classifier: the reference's own Classifier (eval mode) and conditioning function."""
     with np.load(os.path.join(GOLDEN, f"classifier_{tag}.npz")) as z:

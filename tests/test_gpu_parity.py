@@ -479,6 +479,55 @@ def test_tabsyn_edm_denoiser():
         assert out.shape == (513, 40) and not bool(out.isnan().any())
 
 
+def test_label_conditioned_denoiser():
+    """IsTargetConditioned.EMBEDDING with classes (MODEL:583-585, 610-612) against the reference's own outputs
+    (tests/golden/label_label3.npz): the label embedding is extra rows of the time-embedding table
+    (mtk_mlp_set_label_embedding); forward with / without y, mixed_loss rows with y, the sample chain with drawn labels."""
+    import midst_toolkit_amd as mtk
+    from helpers import load_label
+
+    c = load_label()
+    K, Nn, T, D = c["K"], c["Nn"], c["T"], c["Nn"] + int(c["K"].sum())
+
+    def make(T_):
+        net = mtk.MLPDiffusion(D, c["n_labels"], mtk.IsTargetConditioned.EMBEDDING, mtk.DiffusionParameters(list(c["d_layers"]), 0.0))
+        net.load_state_dict(c["params"], strict=True)
+        d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T_, scheduler_type=mtk.SchedulerType("cosine"), device=dev()).to(dev())
+        return d
+
+    d = make(T)
+    d.engine()  # hands the diffusion's T to the denoiser (its table has (labels + 1) x T rows)
+    x, t, y = tt(c["fw_x"]).to(dev()), tt(c["fw_t"]).to(dev()), tt(c["fw_y"]).to(dev())
+    with torch.no_grad():
+        close(d._denoise_fn(x, t, y), tt(c["fw_out_y"]), rtol=RTOL, atol=1e-5)
+        close(d._denoise_fn(x, t), tt(c["fw_out_none"]), rtol=RTOL, atol=1e-5)
+    lm, lg = d.mixed_loss_rows(tt(c["ml_x0"]).to(dev()), timestep=tt(c["ml_t"]).to(dev()), noise=tt(c["ml_eps"]).to(dev()),
+                               uniform=tt(c["ml_u"]).to(dev()), y=tt(c["ml_y"]).to(dev()))
+    close(lg, tt(c["ml_lg_rows"]), rtol=RTOL)
+    assert abs(float(lm.mean().cpu()) - float(c["ml_means"][0])) <= RTOL * abs(float(c["ml_means"][0]))
+    torch.manual_seed(3)
+    with torch.no_grad():  # the unmodified entry point: y travels in ``outputs``
+        m, g = d.mixed_loss(tt(c["ml_x0"]).to(dev()), {"y": tt(c["ml_y"]).to(dev())})
+    assert bool(torch.isfinite(m)) and bool(torch.isfinite(g))
+    # the chain: labels as the reference drew them from target_dist
+    d2 = make(c["ch_T"])
+    noise = [tt(n).to(dev()) for n in c["ch_noise"]]
+    noise[0] = noise[0].float()
+    inj = {"z0": tt(c["ch_z0"]).to(dev()), "noise": noise, "y": tt(c["ch_y"]).long(), "u0": tt(c["ch_u0"]).to(dev()),
+           "u": [tt(v).to(dev()) for v in c["ch_u"]]}
+    got, outs = d2.sample(c["ch_z0"].shape[0], torch.tensor([0.2, 0.5, 0.3]), _injected=inj)
+    want = tt(c["ch_sample"])
+    assert torch.equal(outs["y"].cpu().long(), tt(c["ch_y"]).long())
+    assert torch.equal(got[:, Nn:], want[:, Nn:])
+    close(got[:, :Nn], want[:, :Nn], rtol=RTOL, atol=1e-4)
+    # what stays off the path says so
+    with pytest.raises(NotImplementedError):
+        mtk.ClavaDDPMTrainer(d, None, 1e-3, 0.0, 1, device=dev())
+    reg = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.EMBEDDING, mtk.DiffusionParameters([64, 64], 0.0)).to(dev())
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        reg(x, t, torch.zeros((x.shape[0], 1), device=dev()))
+
+
 def test_dropout_configured_denoiser_runs_in_eval_mode():
     """MODEL:162-180: a denoiser configured with dropout > 0 loads and, in eval mode (Dropout = identity: how scoring and sampling
     call it), gives the dropout-free network's outputs; in training mode the HIP path refuses instead of silently dropping nothing."""

@@ -262,3 +262,33 @@ def test_edm_restatement_bit_exact():
     assert abs(float(loss.mean(-1).mean()) - float(c["loss_mean"])) <= 1e-6 * float(c["loss_mean"])
     got = orc.edm_sample(p, tt(c["s_latents"]), [tt(n) for n in c["s_noise"]], dt, c["num_steps"])
     assert float((got - tt(c["s_sample"])).abs().max()) <= 1e-4 * float(tt(c["s_sample"]).abs().max())
+
+
+def test_label_conditioned_denoiser_restatement():
+    """IsTargetConditioned.EMBEDDING with classes (MODEL:583-585, 610-612; tests/golden/label_label3.npz, generated by running the
+    reference): the oracle's denoiser with and without ``y``, the mixed_loss rows with ``y`` (GMD:1042) and the ``sample`` chain
+    with the drawn labels (GMD:1401-1406) reproduce the reference's outputs."""
+    from tests.helpers import load_label
+
+    c = load_label()
+    p, K, Nn, T = c["params"], c["K"], c["Nn"], c["T"]
+    x, t, y = tt(c["fw_x"]), tt(c["fw_t"]), tt(c["fw_y"])
+
+    def same(got, want, tol=1e-6):
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+    same(orc.mlp_forward(p, x, t, y=y), tt(c["fw_out_y"]))
+    same(orc.mlp_forward(p, x, t), tt(c["fw_out_none"]))
+    assert float((tt(c["fw_out_y"]) - tt(c["fw_out_none"])).abs().max()) > 1e-2  # the labels matter in this fixture
+    s = orc.make_schedule(T, "cosine")
+    lm, lg, m_mean, g_mean = orc.mixed_loss(s, K, Nn, p, tt(c["ml_x0"]), tt(c["ml_t"]), tt(c["ml_eps"]), tt(c["ml_u"]), y=tt(c["ml_y"]))
+    same(lg, tt(c["ml_lg_rows"]), 1e-5)
+    assert abs(float(lm.mean()) - float(c["ml_means"][0])) <= 1e-4 * abs(float(c["ml_means"][0]))
+    s2 = orc.make_schedule(c["ch_T"], "cosine")
+    noise = [tt(n) for n in c["ch_noise"]]
+    noise[0] = noise[0].float()
+    got = orc.sample_chain(s2, K, Nn, p, tt(c["ch_z0"]), tt(c["ch_u0"]), noise, [tt(u) for u in c["ch_u"]], y=tt(c["ch_y"]))
+    want = tt(c["ch_sample"])
+    assert torch.equal(got[:, Nn:], want[:, Nn:])
+    same(got[:, :Nn], want[:, :Nn], 1e-4)

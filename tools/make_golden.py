@@ -587,6 +587,88 @@ def gen_edm(tag="latent24", d_in=24, dim_t=128, B=96, num_steps=10):
     print(f"edm {tag}: loss mean {float(out['loss_mean']):.4f}, sample |x| {float(np.abs(out['s_sample']).mean()):.3f}")
 
 
+def gen_label_embedding(tag="label3", K=(3, 4), Nn=3, d_layers=(64, 64), T=50, B=48, n_labels=3, T_chain=8):
+    """IsTargetConditioned.EMBEDDING with classes (MODEL:583-585, 610-612): the reference's denoiser forward with and without
+    ``y``, its mixed_loss rows with injected noise and ``y`` (GMD:1042), and a whole ``sample`` chain whose labels are drawn from
+    ``target_dist`` (GMD:1401) - every draw captured."""
+    K = np.asarray(K, dtype=np.int64)
+    C, S = len(K), int(K.sum())
+    D = Nn + S
+    g = torch.Generator().manual_seed(77)
+    params = orc.init_mlp_params(D, list(d_layers), seed=9)
+    params["label_embedding.weight"] = torch.randn((n_labels, 128), generator=g)
+
+    def make(T_):
+        dp = model.DiffusionParameters(layers_dimensions=list(d_layers), dropout=0.0)
+        net = model.MLPDiffusion(D, n_labels, IsTargetConditioned.EMBEDDING, dp)
+        net.load_state_dict(params, strict=True)
+        net.eval()
+        diff = gmd.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T_, scheduler_type=gmd.SchedulerType.COSINE, device=CPU)
+        diff.eval()
+        return diff
+
+    diff = make(T)
+    out: dict[str, np.ndarray] = dict(K=K, Nn=Nn, d_layers=np.asarray(d_layers), T=T, n_labels=n_labels)
+    out.update({"p_" + k: v.numpy() for k, v in params.items()})
+    # ---- denoiser forward
+    x = torch.randn((B, D), generator=g)
+    t = torch.randint(0, T, (B,), generator=g)
+    y = torch.randint(0, n_labels, (B, 1), generator=g)  # [B, 1]: MODEL:611 squeezes
+    with torch.no_grad():
+        out.update(fw_x=x.numpy(), fw_t=t.numpy(), fw_y=y.numpy(), fw_out_y=diff._denoise_fn(x, t, y).numpy(),
+                   fw_out_none=diff._denoise_fn(x, t).numpy())
+    # ---- mixed_loss: one whole call with captured draws, then the per-record rows from the injected pieces
+    x0 = synth_rows(B, K, Nn, g)
+    yl = torch.randint(0, n_labels, (B,), generator=g)
+    log: list = []
+    torch.manual_seed(99)
+    with capture_rng(log), torch.no_grad():
+        m_mean, g_mean = diff.mixed_loss(x0, {"y": yl})
+    t = log[0][1].clone()
+    eps = log[1][1]
+    us = [e[1] for e in log[2:]]
+    with torch.no_grad():
+        x_num_t = diff.gaussian_q_sample(x0[:, :Nn], t, noise=eps)
+        log_x0 = du.index_to_log_onehot(x0[:, Nn:].long(), torch.from_numpy(K))
+        it = iter(us)
+        saved = torch.rand_like
+        torch.rand_like = lambda ref: next(it)
+        try:
+            log_xt = diff.q_sample(log_features_start=log_x0, timestep=t)
+        finally:
+            torch.rand_like = saved
+        m_out = diff._denoise_fn(torch.cat([x_num_t, log_xt], dim=1), t, yl)
+        lm_rows = diff._multinomial_loss(m_out[:, Nn:], log_x0, log_xt, t, torch.ones_like(t).float() / T) / C
+        lg_rows = diff._gaussian_loss(m_out[:, :Nn], x0[:, :Nn], x_num_t, t, eps)
+    assert abs(float(lm_rows.mean()) - float(m_mean)) < 1e-6 and abs(float(lg_rows.mean()) - float(g_mean)) < 1e-6
+    out.update(ml_x0=x0.numpy(), ml_y=yl.numpy(), ml_t=t.numpy(), ml_eps=eps.numpy(), ml_u=torch.cat(us, dim=1).numpy(),
+               ml_lm_rows=lm_rows.numpy(), ml_lg_rows=lg_rows.numpy(), ml_means=np.array([m_mean.item(), g_mean.item()], dtype=np.float32))
+    # ---- sample: labels drawn from target_dist
+    diff2 = make(T_chain)
+    Bc = 32
+    log2: list = []
+    torch.manual_seed(4321)
+    with capture_rng(log2):
+        smp, outs = diff2.sample(Bc, torch.tensor([0.2, 0.5, 0.3]))
+    kinds = [e[0] for e in log2]
+    assert kinds[0] == "randn" and kinds[1 + C] == "multinomial"
+    out["ch_z0"] = log2[0][1].numpy()
+    out["ch_u0"] = torch.cat([e[1] for e in log2[1:1 + C]], dim=1).numpy()
+    out["ch_y"] = log2[1 + C][1].numpy()
+    assert torch.equal(outs["y"].cpu().long(), log2[1 + C][1].long())
+    pos = 2 + C
+    ns, uss = [], []
+    for i in range(T_chain):
+        assert kinds[pos] == "randn_like"
+        ns.append(log2[pos][1].double().numpy())
+        uss.append(torch.cat([e[1] for e in log2[pos + 1:pos + 1 + C]], dim=1).numpy())
+        pos += 1 + C
+    assert pos == len(log2)
+    out.update(ch_T=np.array(T_chain), ch_noise=np.stack(ns), ch_u=np.stack(uss), ch_sample=smp.numpy())
+    np.savez_compressed(os.path.join(OUT, f"label_{tag}.npz"), **out)
+    print(f"label {tag}: B={B} D={D} means={m_mean.item():.6f},{g_mean.item():.6f}")
+
+
 def gen_loader():
     """Batches of the reference's FastTensorDataLoader over two shuffled epochs (data_loaders.py:486-551)."""
     from midst_toolkit.models.clavaddpm.data_loaders import FastTensorDataLoader
@@ -709,6 +791,9 @@ def main():
     if "--edm-only" in sys.argv:
         gen_edm()
         return
+    if "--label-only" in sys.argv:
+        gen_label_embedding()
+        return
     if "--ddimx-only" in sys.argv:
         gen_ddim_family()
         return
@@ -738,6 +823,7 @@ def main():
         gen_ddim("B_ragged", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
         gen_ddim_family()
         gen_edm()
+        gen_label_embedding()
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
