@@ -1459,6 +1459,7 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
                             const float* u, float* x_in, int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed,
                             uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null context");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !x0 || !t || !x_in) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
     if (ctx->C > 0 && !xt_idx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: xt_idx is required when C > 0");
     if (x0_ld < ctx->Nn + ctx->C) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: x0_ld %lld < Nn + C = %d", (long long)x0_ld, ctx->Nn + ctx->C);
@@ -1485,6 +1486,7 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
                              int64_t x0_ld, const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi,
                              float* loss_gauss, uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: null context");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !model_out || !t) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: null pointer or negative B");
     if (loss_multi && ctx->C > 0 && (!x0 || !xt_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: x0 and xt_idx are required for the multinomial loss");
     if (x0 && x0_ld < ctx->Nn + ctx->C) MTK_FAIL(MTK_ERR_ARG, "mtk_loss_rows: x0_ld too small");
@@ -1515,6 +1517,7 @@ extern "C" int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int firs
                                         uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: null context");
     if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: t = %d outside [0, %d)", t, ctx->T);
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !model_out || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_p_sample_step: null pointer or negative B");
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
@@ -1556,6 +1559,7 @@ extern "C" int mtk_ddim_step_ex(mtk_ctx* ctx, int64_t B, int t, double eta, cons
                                 int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: null context");
     if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: t = %d outside [0, %d)", t, ctx->T);
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !model_out || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: null pointer or negative B");
     if (!(eta >= 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_step: eta = %g must be >= 0", eta);
     if (B == 0) return MTK_OK;
@@ -1594,6 +1598,7 @@ extern "C" int mtk_ddim_reverse_step(mtk_ctx* ctx, int64_t B, int t, const float
                                      float* x_in_next, int64_t xi_rs, int64_t xi_cs, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_reverse_step: null context");
     if (t < 0 || t >= ctx->T) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_reverse_step: t = %d outside [0, %d)", t, ctx->T);
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !model_out || (ctx->Nn > 0 && !z)) MTK_FAIL(MTK_ERR_ARG, "mtk_ddim_reverse_step: null pointer or negative B");
     if (B == 0 || ctx->Nn == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
@@ -1614,6 +1619,7 @@ extern "C" int mtk_ddim_reverse_step(mtk_ctx* ctx, int64_t B, int t, const float
 extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, double* z, int32_t* z_idx,
                                float* x_in, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null context");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !x_in || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null pointer or negative B");
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
@@ -1627,6 +1633,7 @@ extern "C" int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out
                                  int64_t x0_ld, const float* x_t, int64_t xt_rs, int64_t xt_cs, const int64_t* t, double* loss,
                                  mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: null context");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || ctx->Nn < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: negative B or no numeric columns");
     if (B == 0) return MTK_OK;
     if (!model_out || !x0 || !x_t || !t || !loss) MTK_FAIL(MTK_ERR_ARG, "mtk_gauss_kl_rows: null pointer");
@@ -1645,6 +1652,7 @@ extern "C" int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out
 extern "C" int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, double* sample,
                                  mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_decode: null context");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !sample) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_decode: null pointer or negative B");
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));

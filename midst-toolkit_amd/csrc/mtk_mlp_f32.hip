@@ -455,6 +455,7 @@ extern "C" int mtk_mlp_forward_noalloc(mtk_ctx* c, int64_t B, const float* x, in
                                        int t_scalar, float* out, int64_t o_rs, int64_t o_cs, mtk_stream stream) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_noalloc: null context");
     if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward_noalloc: call mtk_mlp_set_weights first");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !x || !out) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_noalloc: null pointer or negative B");
     if (!t && (t_scalar < 0 || t_scalar >= c->T)) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_noalloc: t_scalar = %d outside [0, %d)", t_scalar, c->T);
     if (B > kNoallocRows)
@@ -474,6 +475,7 @@ extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_
                                int t_scalar, float* out, int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: null context");
     if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward: call mtk_mlp_set_weights first");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !x || !out) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: null pointer or negative B");
     if (!t && (t_scalar < 0 || t_scalar >= c->T)) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward: t_scalar = %d outside [0, %d)", t_scalar, c->T);
     if (B == 0) return MTK_OK;

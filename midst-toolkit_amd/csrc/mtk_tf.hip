@@ -72,6 +72,7 @@ extern "C" int mtk_tf_score(mtk_ctx* c, int64_t B, int P, const float* x, int64_
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_tf_score: null context");
     if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_tf_score: call mtk_mlp_set_weights first");
     if (c->S != 0) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_tf_score: the denoiser takes %d one-hot columns; TF scoring feeds the numeric block only (TF:86-91)", c->S);
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || P < 1 || n_t < 0 || !x || !noise || !score || (n_t > 0 && !t_list_host)) MTK_FAIL(MTK_ERR_ARG, "mtk_tf_score: bad argument");
     if (x_ld < c->Nn) MTK_FAIL(MTK_ERR_ARG, "mtk_tf_score: x_ld %lld < Nn %d", (long long)x_ld, c->Nn);
     for (int k = 0; k < n_t; ++k) {

@@ -1119,6 +1119,7 @@ extern "C" int mtk_clf_create(int device, int T, int D_in, int dim_t, int n_lin,
 extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,
                                 float* logits, float* grad, mtk_stream stream) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_guidance: null classifier");
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !x || !t || (grad && !y)) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_guidance: null pointer or negative B");
     if (x_ld < c->D_in) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_guidance: x_ld %lld < input width %d", (long long)x_ld, c->D_in);
     if (B == 0 || (!logits && !grad)) return MTK_OK;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_affine_inverse(int64_t B, int ncol, int
 
 extern "C" int mtk_affine_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, int kind, const double* p0,
                                   const double* p1, double* out, int64_t out_ld, mtk_stream stream) {
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || n_columns < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_affine_inverse: bad shape");
     if (kind != 0 && kind != 1) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_affine_inverse: kind = %d (0 = standard, 1 = min-max)", kind);
     if (B == 0) return MTK_OK;
@@ -101,6 +102,7 @@ extern "C" int mtk_affine_inverse(int device, int64_t B, int n_columns, const do
 extern "C" int mtk_quantile_inverse(int device, int64_t B, int n_columns, const double* x, int64_t x_ld, const double* quantiles,
                                     const double* references, int n_quantiles, int output_normal, double* out, int64_t out_ld,
                                     mtk_stream stream) {
+    if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || n_columns < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_quantile_inverse: bad shape");
     if (B > 0 && (!x || !quantiles || !references || !out)) MTK_FAIL(MTK_ERR_ARG, "mtk_quantile_inverse: null pointer");
     if (n_quantiles < 2 || n_quantiles > kMaxQ) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_quantile_inverse: n_quantiles = %d outside [2, %d]", n_quantiles, kMaxQ);

@@ -675,6 +675,36 @@ def test_sample_all_and_philox_mode():
         assert float((freq - 1.0 / int(K)).abs().max()) < 0.03
 
 
+def test_empty_batches():
+    """Zero records in, zero rows out: every entry point of the path returns without a launch (the reference's ops on
+    empty tensors give empty tensors too)."""
+    from midst_toolkit_amd import scoring
+
+    c = load_case("B_ragged")
+    d = build(c)
+    D, Nn = c["D"], c["Nn"]
+    x0 = tt(c["x0"]).to(dev())[:0]
+    with torch.no_grad():
+        out = d._denoise_fn(torch.empty((0, D), device=dev()), torch.empty((0,), dtype=torch.int64, device=dev()))
+    assert out.shape == (0, D)
+    lm, lg = d.mixed_loss_rows(x0, timestep=torch.empty((0,), dtype=torch.int64, device=dev()), noise=torch.empty((0, Nn), device=dev()),
+                               uniform=torch.empty((0, c["S"]), device=dev()))
+    assert lm.shape == (0,) and lg.shape == (0,)
+    a = load_case("A_numeric")
+    da = build(a)
+    sc = scoring.score_records(da, tt(a["x0"]).to(dev())[:0], tt(a["tf_noise"]).to(dev()), [3, 7], 0)
+    assert sc.shape[1] == 0 and sc.numel() == 0
+    with pytest.raises(RuntimeError):  # like the reference: torch.multinomial (GMD:1401) refuses to draw zero labels
+        d.sample(0, torch.ones(1))
+    eng = d.engine()  # the kernels of a reverse step on zero rows
+    z, zi = torch.empty((Nn, 0), dtype=torch.float64, device=dev()), torch.empty((c["C"], 0), dtype=torch.int32, device=dev())
+    e0 = torch.empty((D, 0), device=dev())
+    eng.sample_init(0, None, None, z, zi, e0, (1, 0), 5, 0)
+    eng.p_sample_step(0, 3, False, e0, (1, 0), z, zi, None, None, e0, (1, 0), 5, 0)
+    smp = torch.empty((0, Nn + c["C"]), dtype=torch.float64, device=dev())
+    eng.sample_decode(0, z, zi, smp)
+
+
 def test_bad_arguments_raise():
     c = load_case("A_numeric")
     d = build(c)
