@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["A_numeric", "B_ragged", "M_mixed", "N_tf", "L_catonly"]
+CASES = ["A_numeric", "B_ragged", "M_mixed", "N_tf", "L_catonly", "K1_single"]
 
 
 @pytest.fixture(scope="session")

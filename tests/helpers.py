@@ -9,7 +9,7 @@ import torch
 from oracle import diffusion_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["A_numeric", "B_ragged", "M_mixed", "N_tf", "L_catonly"]
+CASES = ["A_numeric", "B_ragged", "M_mixed", "N_tf", "L_catonly", "K1_single"]
 
 
 def load_case(tag: str) -> dict:

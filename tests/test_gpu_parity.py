@@ -273,7 +273,7 @@ def test_reverse_steps(tag):
             assert torch.equal(x_next[Nn:].t().cpu(), want_oh)
 
 
-@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly"])
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly", "K1_single"])
 def test_full_chain(tag):
     c = load_case(tag)
     Tc = int(c["ch_T"])
@@ -1133,7 +1133,7 @@ def _big_mixed_batch(c, B, seed=11):
     return x0, t, torch.randn((B, Nn), generator=g), torch.rand((B, S), generator=g)
 
 
-@pytest.mark.parametrize("tag", ["M_mixed", "B_ragged"])
+@pytest.mark.parametrize("tag", ["M_mixed", "B_ragged", "K1_single"])
 def test_fast_math_against_oracle(tag, monkeypatch):
     global TIE_MARGIN
     c = load_case(tag)

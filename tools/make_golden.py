@@ -843,6 +843,8 @@ def main_cases():
     gen_case("N_tf", [0], 20, [512] * 4, 1000, 64, P=4)
     # L: linear schedule, categorical only
     gen_case("L_catonly", [4, 4, 5], 0, [64, 64], 100, 48, sched="linear", T_chain=40)
+    # K1: categorical columns with a single level (log K = 0; the posterior has no "other" column)
+    gen_case("K1_single", [1, 3, 1], 2, [32, 32], 50, 32, T_chain=6)
 
 
 if __name__ == "__main__":
