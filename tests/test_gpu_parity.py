@@ -705,6 +705,55 @@ def test_empty_batches():
     eng.sample_decode(0, z, zi, smp)
 
 
+def test_batches_beyond_32_bit_element_indices():
+    """2^24 + 5 records of shape M: the column-major intermediates hold 2.0e9 elements (past 2^31) and 8 GB each.  In-kernel
+    Philox noise is keyed by (seed, row0 + row), so the last rows of the big batch must equal, bit for bit, a small batch of
+    those rows submitted with row0 = their offset - through noising, the fused bf16 denoiser and the loss kernel."""
+    c = load_case("M_mixed")
+    d = build(c, precision="bf16")
+    d.rng, d.math = "philox", "fast"
+    eng = d.engine()
+    Nn, C, D, K = c["Nn"], c["C"], c["D"], c["K"]
+    B, n = (1 << 24) + 5, 300
+    g = torch.Generator(device=dev()).manual_seed(8)
+    x0 = torch.cat([torch.randn((B, Nn), device=dev(), generator=g)] +
+                   [torch.randint(0, int(k), (B, 1), device=dev(), generator=g).float() for k in K], 1)
+    t = torch.randint(0, c["T"], (B,), device=dev(), generator=g)
+
+    def run(x0_, t_, rows, row0):
+        x_in = torch.empty((D, rows), device=dev())
+        idx = torch.empty((C, rows), dtype=torch.int32, device=dev())
+        out = torch.empty((D, rows), device=dev())
+        lm, lg = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+        eng.q_sample(x0_, t_, None, None, x_in, (1, rows), idx, 77, row0)
+        eng.mlp_forward(x_in, t_, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows)
+        eng.loss_rows(out, (1, rows), x0_, idx, None, t_, lm, lg, 77, row0)
+        return x_in, idx, out, lm, lg
+
+    big = run(x0, t, B, 0)
+    assert bool(torch.isfinite(big[3]).all()) and bool(torch.isfinite(big[4]).all())
+    for lo in (B - n, (1 << 23) + 11):  # the tail (past element 2^31 of every column block) and the middle
+        small = run(x0[lo:lo + n].contiguous(), t[lo:lo + n].contiguous(), n, lo)
+        for a_, b_ in zip(big[:3], small[:3]):
+            assert torch.equal(a_[:, lo:lo + n], b_), lo
+        assert torch.equal(big[3][lo:lo + n], small[3]) and torch.equal(big[4][lo:lo + n], small[4]), lo
+    # one reverse step on the same batch (fp64 state, Philox draws keyed by the global row)
+    def step(rows, row0, out_cm, z, zi):
+        x_next = torch.empty((D, rows), device=dev())
+        eng.p_sample_step(rows, 400, False, out_cm, (1, rows), z, zi, None, None, x_next, (1, rows), 91, row0)
+        return x_next
+
+    z = torch.randn((Nn, B), device=dev(), generator=g, dtype=torch.float64)
+    zi = big[1].clone()
+    lo = B - n
+    zs, zis = z[:, lo:].clone().contiguous(), zi[:, lo:].clone().contiguous()
+    xn_big = step(B, 0, big[2], z, zi)
+    xn_small = step(n, lo, big[2][:, lo:].contiguous(), zs, zis)
+    assert torch.equal(xn_big[:, lo:], xn_small) and torch.equal(z[:, lo:], zs) and torch.equal(zi[:, lo:], zis)
+    del big, z, zi, xn_big
+    torch.cuda.empty_cache()
+
+
 def test_bad_arguments_raise():
     c = load_case("A_numeric")
     d = build(c)
