@@ -321,195 +321,6 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived at the consumer, in rank order
         last = (a.warmup + a.steps - 1) % nbuf
-        cdev = dev if backend == "nccl" else torch.device("cpu")
-        mine = scores[last].flatten()[:4].to(cdev)
-        every = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        if rank == 0:
-            assert torch.equal(gathered[last][0], scores[last])
-            for r in range(world):
-                assert torch.equal(gathered[last][r].flatten()[:4].cpu(), every[r].cpu()), r
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    assert x.shape == (rows, Nn + len(K)) and bool(torch.isfinite(x).all())
-    # the two kernels of one reverse step, timed alone at the chain's batch size
-    eng = d.engine()
-    x_in = torch.randn((D, rows), device=dev)
-    out = torch.empty((D, rows), device=dev)
-    z = torch.randn((Nn, rows), device=dev, dtype=torch.float64)
-    zi = torch.randint(0, 10, (len(K), rows), device=dev, dtype=torch.int32)
-    t_mlp = timeit(lambda: eng.mlp_forward(x_in, 500, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows))
-    t_step = timeit(lambda: eng.p_sample_step(rows, 500, False, out, (1, rows), z, zi, None, None, x_in, (1, rows), seed=3))
-    fl = flops_per_eval(D, 128, [hidden] * 4)
-    b_step = Nn * 8 * 2 + Nn * 4 + int(K.sum()) * 4 + len(K) * 4 * 2 + D * 4  # 1,360 B per row-step (Philox)
-    return {"sampled_rows_per_s": world * rows / dt, "row_steps_per_s": world * rows * T / dt, "rows_per_gpu": rows, "T": T, "seconds": dt,
-            "denoiser": f"4x{hidden} bf16", "rng": "philox (in-kernel)", "math": "fast", "launches": 2 * T + 2,
-            "roofline_denoiser": {"bound": "mfma", "achieved": rows * fl / t_mlp / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                                  "frac": rows * fl / t_mlp / 1e12 / PEAK_TFLOPS["bf16"], "kernel_ms": t_mlp * 1e3, "flops_per_row_step": fl},
-            "roofline_step": {"bound": "hbm", "achieved": rows * b_step / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": rows * b_step / t_step / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_step * 1e3, "bytes_per_row_step": b_step},
-            "whole_loop_mfma_frac": rows * T * fl / dt / 1e12 / PEAK_TFLOPS["bf16"]}
-
-
-def bench_mixed_loss(mtk, dev, rows):
-    """Shape-M mixed_loss (q_sample -> fused bf16 denoiser -> loss_rows), in-kernel Philox noise, math "fast"."""
-    K, Nn, T = np.array([10] * 10), 20, 1000
-    C, S = len(K), int(K.sum())
-    D = Nn + S
-    torch.manual_seed(0)
-    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([512] * 4, 0.0))
-    net.precision = "bf16"
-    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
-    d.precision, d.rng = "bf16", "philox"
-    eng = d.engine()
-    g = torch.Generator().manual_seed(20250821)
-    x0 = torch.cat([torch.randn((rows, Nn), generator=g).clamp(-5.2, 5.2)] + [torch.randint(0, int(k), (rows, 1), generator=g).float() for k in K], 1).to(dev)
-    t = torch.randint(0, T, (rows,), generator=g).to(dev)
-    x_in = torch.empty((D, rows), device=dev)
-    out = torch.empty((D, rows), device=dev)
-    idx = torch.empty((C, rows), dtype=torch.int32, device=dev)
-    lm, lg = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
-    q = lambda: eng.q_sample(x0, t, None, None, x_in, (1, rows), idx, seed=1)  # noqa: E731
-    m = lambda: eng.mlp_forward(x_in, t, out=out, precision="bf16", x_strides=(1, rows), out_strides=(1, rows), B=rows)  # noqa: E731
-    lo = lambda: eng.loss_rows(out, (1, rows), x0, idx, None, t, lm, lg, seed=1)  # noqa: E731
-    tq, tm, tl = timeit(q), timeit(m), timeit(lo)
-    tot = timeit(lambda: d.mixed_loss_rows(x0, timestep=t, seed=7))
-    fl = flops_per_eval(D, 128, [512] * 4)
-    b_q = (Nn + C) * 4 + 8 + D * 4 + C * 4          # 648 B per row (SURVEY 8d, Philox)
-    b_l = D * 4 + (Nn + C) * 4 + C * 4 + 8 + 8      # 656 B per row
-    hbm = lambda b, s: {"bound": "hbm", "achieved": rows * b / s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rows * b / s / 1e9 / HBM_PEAK_GBS,  # noqa: E731
-                        "kernel_ms": s * 1e3, "bytes_per_row": b}
-    return {"evals_per_s": rows / tot, "rows": rows, "ms": tot * 1e3, "denoiser": "4x512 bf16 (fused)", "rng": "philox (in-kernel)", "math": "fast",
-            "roofline_q_sample": hbm(b_q, tq), "roofline_loss_rows": hbm(b_l, tl),
-            "roofline_denoiser": {"bound": "mfma", "achieved": rows * fl / tm / 1e12, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                                  "frac": rows * fl / tm / 1e12 / PEAK_TFLOPS["bf16"], "kernel_ms": tm * 1e3, "flops_per_eval": fl},
-            "note": "each kernel's time includes the 8 B/row pass that turns rows with an out-of-range timestep into NaN"}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--records", type=int, default=0, help="records per GPU (weak; default 100000) or in total (strong; default 1000000)")
-    ap.add_argument("--nt", type=int, default=0, help="timesteps per step (default: all 1000 in weak mode, 100 in strong mode)")
-    ap.add_argument("--P", type=int, default=0, help="noise draws per record (default 1 weak, 4 strong)")
-    ap.add_argument("--hidden", type=int, default=512)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
-    ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--sample-rows", type=int, default=262144)
-    a = ap.parse_args()
-
-    if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr
-        import faulthandler
-
-        faulthandler.dump_traceback_later(120, exit=True)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
-    # MTK_BENCH_BACKEND=gloo rehearses the N > 1 control flow with several ranks on one card (RCCL refuses that)
-    backend = os.environ.get("MTK_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    import midst_toolkit_amd as mtk
-    from midst_toolkit_amd.distributed import shard_range
-
-    strong = a.mode == "strong"
-    T, Nn, seed = 1000, 20, 20250821
-    P = a.P or (4 if strong else 1)
-    nt = a.nt or (100 if strong else T)
-    total = a.records or (1_000_000 if strong else 100_000)
-    if strong:
-        lo, hi = shard_range(total, rank, world)
-        n_local, n_max = hi - lo, shard_range(total, 0, world)[1]
-        n_global = total
-    else:
-        lo, n_local, n_max, n_global = rank * total, total, total, total * world
-    hidden = [a.hidden] * 4
-    torch.manual_seed(0)
-    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(hidden, 0.0))
-    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    net.precision = a.precision
-    diff = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev).to(dev)
-    diff.precision = a.precision
-
-    # this rank's shard, resident; rows are a pure function of their global index (strong mode: any world size scores
-    # the same 1M records)
-    g = torch.Generator().manual_seed(seed)
-    if strong:
-        x = torch.randn((total, Nn), generator=g).clamp(-5.2, 5.2)[lo:lo + n_local].contiguous().to(dev)
-    else:
-        x = torch.randn((n_local, Nn), generator=torch.Generator().manual_seed(seed + rank)).clamp(-5.2, 5.2).to(dev)
-    noise = torch.randn((P, Nn), generator=torch.Generator().manual_seed(seed)).to(dev)  # shared table
-    eng = diff.engine()
-    # N > 1: the only exchange of the path is the gather of the score blocks to the consumer (rank 0).  It runs on RCCL's
-    # own stream while the next step's kernels compute into the other buffer (double buffered); a step waits,
-    # stream-side, only for the gather that last used its buffer.  Every gather is drained inside the timed region.
-    nbuf = 2 if world > 1 else 1
-    scores = [torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(nbuf)]  # padded to the largest shard
-    gathered = [[torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(nbuf)] if (world > 1 and rank == 0) else None
-    pending = [None] * nbuf
-
-    ragged = n_local != n_max  # strong scaling with total % world != 0: score into a compact block, copy into the padded buffer
-    compact = torch.empty((nt, n_local, P), dtype=torch.float32, device=dev) if ragged else None
-
-    def step(i, events=None):
-        b = i % nbuf
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        ts = [(i * nt + k) % T for k in range(nt)]
-        if events:
-            events[0].record()
-        eng.tf_score(x, noise, ts, 0, a.precision, out=compact if ragged else scores[b])
-        if ragged:
-            scores[b][:, :n_local].copy_(compact)
-        if events:
-            events[1].record()
-        if world > 1:
-            if backend == "nccl":
-                pending[b] = dist.gather(scores[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
-            else:  # gloo rehearsal of the control flow: staged through host tensors
-                pending[b] = _HostGather(dist, scores[b], gathered[b] if rank == 0 else None, world, rank)
-
-    def barrier():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(a.warmup):
-        step(i)
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i, ev[i])
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived at the consumer, in rank order
-        last = (a.warmup + a.steps - 1) % nbuf
         mine = scores[last].flatten()[:4].cpu()
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine) if backend != "nccl" else dist.all_gather(every := [t.to(dev) for t in every], mine.to(dev))
