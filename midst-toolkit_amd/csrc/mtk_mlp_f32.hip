@@ -255,6 +255,7 @@ extern "C" int mtk_mlp_set_label_embedding(mtk_ctx* c, const float* rows_dev, in
     c->n_label = 0;
     c->t_period = 0;
     c->label_dim = 0;
+    c->have_weights = false;  // the table built by the last mtk_mlp_set_weights no longer matches: forward calls fail until it is called again
     if (n_labels == 0) return MTK_OK;
     if (!rows_dev || n_labels < 0 || dim < 2 || period < 1) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_label_embedding: bad argument");
     if ((int64_t)(n_labels + 1) * period != c->T)

@@ -158,10 +158,11 @@ class MLPDiffusion(nn.Module):
         self._engine, self._engine_shared, self._synced_key = engine, True, None
 
     def engine(self, device: torch.device) -> Engine:
-        if self._engine is None or self._engine.device != torch.device(device):
+        rows = self.num_timesteps * (self.num_classes + 1 if self._label_rows() else 1)  # table rows: (label, timestep) pairs
+        stale = self._engine is not None and not self._engine_shared and self._engine.T != rows  # num_timesteps changed (a diffusion object set its T)
+        if self._engine is None or self._engine.device != torch.device(device) or stale:
             if self._engine is not None and self._engine_shared:
                 raise RuntimeError("denoiser and diffusion context live on different devices")
-            rows = self.num_timesteps * (self.num_classes + 1 if self._label_rows() else 1)  # table rows: (label, timestep) pairs
             buf = schedule.buffer_values(schedule.SchedulerType.COSINE, rows)
             tabs = {**buf, **schedule.posterior_values(buf)}
             self._engine = Engine(device, rows, self.input_dimension, [0], tabs)

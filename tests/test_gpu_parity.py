@@ -496,6 +496,8 @@ def test_label_conditioned_denoiser():
         return d
 
     d = make(T)
+    with torch.no_grad():  # used stand-alone first (1000 timesteps by default): the context is rebuilt when the diffusion hands over its T
+        d._denoise_fn.to(dev())(tt(c["fw_x"]).to(dev()), tt(c["fw_t"]).to(dev()), tt(c["fw_y"]).to(dev()))
     d.engine()  # hands the diffusion's T to the denoiser (its table has (labels + 1) x T rows)
     x, t, y = tt(c["fw_x"]).to(dev()), tt(c["fw_t"]).to(dev()), tt(c["fw_y"]).to(dev())
     with torch.no_grad():
