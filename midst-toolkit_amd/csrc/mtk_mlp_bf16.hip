@@ -473,14 +473,22 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
             int hq = hh, Dq = a.D;
             int64_t xcs = a.x_cs;
             asm volatile("" : "+v"(hq), "+s"(Dq), "+s"(xcs));
-            const int64_t base = w.valid ? w.xoff : 0;
+            // Address = [per-lane pointer: the lane's row and its half's first feature, formed once per tile] + [feature * column
+            // stride: uniform, formed on the scalar unit]: a 64-bit add per load.  The per-load 64-bit multiply of a per-lane
+            // feature index it replaces cost eight vector instructions per load (1 k per tile, in front of the exposed round trip).
+            const float* row0 = a.x + (w.valid ? w.xoff : 0);
+            const float* pl = row0 + (int64_t)(4 * hq) * xcs;
             static_for<KS0>([&](auto ic) {
                 constexpr int ks = decltype(ic)::value;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int f = feat(ks, hq, j);
-                    const int fc = f < Dq ? f : Dq - 1;
-                    raw[ks * 8 + j] = a.x[base + (int64_t)fc * xcs];
+                    const int cf = feat(ks, 0, j);  // the half-independent part of the feature index (compile time)
+                    const float* p = pl + (int64_t)cf * xcs;
+                    if constexpr ((ks >> 1) == DT - 1) {
+                        // the last 32-feature tile can reach past D: such lanes read the row's first feature (masked below)
+                        if (cf + 4 * hq >= Dq) p = row0;
+                    }
+                    raw[ks * 8 + j] = *p;
                 }
             });
             asm volatile("" ::: "memory");  // the loads stay above this line, unconditional; the masks below cannot pull them down
@@ -596,12 +604,12 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
                     int64_t ocs = a.o_cs;  // opaque for the same reason as in request_x
                     int hq = hh, Dq = a.D;
                     asm volatile("" : "+s"(ocs), "+v"(hq), "+s"(Dq));
-                    float* orow = a.out + cur.row * a.o_rs;
+                    float* ol = a.out + cur.row * a.o_rs + (int64_t)(4 * hq) * ocs;  // per lane, once per tile; + uniform feature offsets
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int f = 32 * nt + 8 * (r >> 2) + 4 * hq + (r & 3);
+                        const int cf = 32 * nt + 8 * (r >> 2) + (r & 3);
                         // only the last tile can reach past D = the number of outputs (DT = ceil(D / 32))
-                        if (nt < DT - 1 || f < Dq) orow[(int64_t)f * ocs] = o[r];
+                        if (nt < DT - 1 || cf + 4 * hq < Dq) ol[(int64_t)cf * ocs] = o[r];
                     }
                 }
             } else {
