@@ -93,20 +93,29 @@ struct Pipe {
     unsigned rd, dma;          // LDS byte offsets: buffer being consumed, buffer being filled
     int lane, wid;
     unsigned rdv;              // rd + lane * 16: the per-lane LDS address of the chunk being consumed (see rotate)
+    const unsigned char* gpc;  // this wave's share of the chunk being requested (+ 4096), set by piece 0
     static constexpr int kExp = EXP;  // 1 = no weight DMA after the prologue, 2 = no chunk barrier, 4 = no layer epilogues
 
-    // piece K (0..7) of the chunk being requested: fragment wid + 4 K; 64 lanes x 16 B, dest = base + lane * 16.
-    // Scalar base + per-lane 32-bit offset (no 64-bit VALU address), and M0 is written but neither saved nor restored:
-    // the compiler keeps nothing in M0 in this kernel (no LDS-direct, GWS or message instruction; checked in the ISA),
-    // and the two extra s_mov per piece were 424 x 2 issue slots per tile.
+    // piece K (0..7) of the chunk being requested: fragment 8 wid + K; 64 lanes x 16 B, dest = base + lane * 16.
+    // Piece 0 sets up the request: M0 = LDS address of the wave's 8-KiB share of the buffer being filled (+ 4096), and a
+    // scalar pointer to the same share of the chunk in the stream; pieces 1..7 are then ONE instruction each - the 13-bit
+    // signed instruction offset of global_load_lds applies to the global AND the LDS address, so (K - 4) KiB walks both.
+    // (Before: per piece an s_add for the destination, the M0 write and its wait state, and a 64-bit scalar add for the
+    // source - 128 pieces per hidden layer.)  M0 has to keep its value between the pieces of a request: the compiler
+    // puts nothing in M0 in this kernel (no LDS-direct, GWS, s_movrel or message instruction; checked in the ISA - the
+    // only M0 accesses are these and dma16's, which saves and restores it).
     template <int K>
     __device__ __forceinline__ void piece() {
         if constexpr (!(EXP & 1)) {
-            const int f = wid + 4 * K;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(dma + (unsigned)f * kFragBytes);
-            const unsigned char* gp = src + (size_t)next * kChunkBytes + (size_t)f * kFragBytes;
             const unsigned voff = (unsigned)lane * 16u;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(dst), "s"(gp) : "memory");
+            if constexpr (K == 0) {
+                const unsigned share = (unsigned)wid * (8u * (unsigned)kFragBytes) + 4096u;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(dma + share);
+                gpc = src + (size_t)next * kChunkBytes + share;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:-4096" : : "v"(voff), "s"(m0v), "s"(gpc) : "memory");
+            } else {
+                asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(gpc), "n"((K - 4) * 1024) : "memory");
+            }
         }
         if constexpr (K == 7) {
             next = (next + 1 == total_chunks) ? 0 : next + 1;
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_fused(FusedArgs a) {
         }
     }
 
-    Pipe<EXP> p{a.wfrag, a.total_chunks, 0, 0u, 0u, lane, wid, (unsigned)lane * 16u};
+    Pipe<EXP> p{a.wfrag, a.total_chunks, 0, 0u, 0u, lane, wid, (unsigned)lane * 16u, a.wfrag};
     p.fetch_all();  // chunk 0 -> buffer 0
     p.fetch_all();  // chunk 1 -> buffer 1
     p.template piece<0>();  // chunk 2 -> buffer 2, the rest of it is requested while chunk 0 is consumed
