@@ -125,22 +125,36 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
     Cursor cx{wq, 0, 0, nullptr}, cw{wq, 0, 0, nullptr};
     auto x_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.X + ((slot / g.nb_n) * 8 + xcd) * G::BM * g.x_ld); };
     auto w_base = [&](int64_t slot) { return reinterpret_cast<const unsigned char*>(g.W + (int64_t)((int)(slot % g.nb_n) * G::BN) * g.w_ld); };
-    auto dma = [&](const unsigned char* gp, unsigned voff, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(gp), "s"(dst)
-                     : "memory");
+    // A wave's n pieces of a block land in n consecutive KiB of LDS.  Piece 0 writes M0 (their middle); every piece carries its
+    // KiB as the instruction offset, which global_load_lds applies to the LDS and to the global address alike - so the scalar
+    // source pointer is handed over with the same offset taken off.  One M0 write and wait state per operand and block instead
+    // of a save / write / wait / restore around every piece.  M0 keeps its value between the pieces: the compiler puts nothing
+    // in M0 in this kernel (checked in the ISA: these are its only M0 accesses).
+    auto dma = [&](const unsigned char* gp, unsigned voff, unsigned dst0, int j, int n) {
+        const int imm = (j - n / 2) * 1024;
+        const unsigned char* gq = gp - imm;
+        if (j == 0) {
+            const unsigned m0v = dst0 + (unsigned)(n / 2) * 1024u;
+            if (n == 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048" : : "v"(voff), "s"(gq), "s"(m0v) : "memory");
+            else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-1024" : : "v"(voff), "s"(gq), "s"(m0v) : "memory");
+            return;
+        }
+        switch (imm) {
+            case -1024: asm volatile("global_load_lds_dwordx4 %0, %1 offset:-1024" : : "v"(voff), "s"(gq) : "memory"); break;
+            case 0: asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gq) : "memory"); break;
+            default: asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voff), "s"(gq) : "memory"); break;
+        }
     };
+    static_assert((G::XPW == 4 || G::XPW == 2) && (G::WPW == 4 || G::WPW == 2), "piece offsets above cover 2 or 4 pieces per wave");
     auto x_op = [&](int j) {  // piece j of this wave's XPW of the record block at the cursor
         if (cx.slot >= slots) return;
         const int chunk = wv * G::XPW + j;
-        dma(cx.base + (int64_t)chunk * 8 * g.x_ld * 2 + xcol(cx.kb) * 2, voff_x[chunk & 1], (unsigned)(cx.buf * kTileX + chunk * 1024));
+        dma(cx.base + (int64_t)chunk * 8 * g.x_ld * 2 + xcol(cx.kb) * 2, voff_x[chunk & 1], (unsigned)(cx.buf * kTileX + wv * G::XPW * 1024), j, G::XPW);
     };
     auto w_op = [&](int j) {
         if (cw.slot >= slots) return;
         const int chunk = wv * G::WPW + j;
-        dma(cw.base + (int64_t)chunk * 8 * g.w_ld * 2 + wcol(cw.kb) * 2, voff_w[chunk & 1], (unsigned)(kWBase + cw.buf * kTileW + chunk * 1024));
+        dma(cw.base + (int64_t)chunk * 8 * g.w_ld * 2 + wcol(cw.kb) * 2, voff_w[chunk & 1], (unsigned)(kWBase + cw.buf * kTileW + wv * G::WPW * 1024), j, G::WPW);
     };
     auto x_advance = [&]() {
         if (cx.slot >= slots) return;
