@@ -122,7 +122,7 @@ def timeit(fn, iters=5, warm=2):
     return float(np.median([s.elapsed_time(e) for s, e in ev])) * 1e-3
 
 
-def bench_sampling(mtk, dev, hidden, rows, dist, world):
+def bench_sampling(mtk, dev, hidden, rows, dist, world, comm=False):
     """Sampled rows/s at T = 1000, shape M, in-kernel Philox noise (math "fast"), bf16 denoiser: every rank runs its own
     chain over `rows` rows (no collective inside the loop); value = world x rows / max-over-ranks time."""
     K, Nn, T = np.array([10] * 10), 20, 1000
@@ -134,13 +134,13 @@ def bench_sampling(mtk, dev, hidden, rows, dist, world):
     d.precision, d.rng, d.results_on_device = "bf16", "philox", True
     d.sample(rows, torch.ones(1), seed=1)  # warm-up: packs the weights, sizes the workspaces
     torch.cuda.synchronize()
-    if world > 1:
+    if comm:
         dist.barrier()
     t0 = time.perf_counter()
     x, _ = d.sample(rows, torch.ones(1), seed=2)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if comm:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -213,6 +213,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--sample-rows", type=int, default=262144)
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="one GPU: initialise an RCCL (nccl) process group of ONE rank and run the N > 1 code path on it - the asynchronous, "
+                         "double-buffered gather of the score blocks, the barriers, the MAX all-reduce of the time (what a one-GPU box can "
+                         "show of SURVEY 8e)")
     a = ap.parse_args()
 
     if os.environ.get("MTK_BENCH_CHECK"):  # rehearsal runs: a hang ends with every thread's stack on stderr
@@ -231,13 +235,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    comm = world > 1 or a.rehearse_rccl  # the collectives of the N > 1 path run (at N = 1: the rehearsal)
+    if comm:
         import torch.distributed as dist
 
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import midst_toolkit_amd as mtk
     from midst_toolkit_amd.distributed import shard_range
@@ -273,9 +281,9 @@ def main():
     # N > 1: the only exchange of the path is the gather of the score blocks to the consumer (rank 0).  It runs on RCCL's
     # own stream while the next step's kernels compute into the other buffer (double buffered); a step waits,
     # stream-side, only for the gather that last used its buffer.  Every gather is drained inside the timed region.
-    nbuf = 2 if world > 1 else 1
+    nbuf = 2 if comm else 1
     scores = [torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(nbuf)]  # padded to the largest shard
-    gathered = [[torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(nbuf)] if (world > 1 and rank == 0) else None
+    gathered = [[torch.empty((nt, n_max, P), dtype=torch.float32, device=dev) for _ in range(world)] for _ in range(nbuf)] if (comm and rank == 0) else None
     pending = [None] * nbuf
 
     ragged = n_local != n_max  # strong scaling with total % world != 0: score into a compact block, copy into the padded buffer
@@ -294,7 +302,7 @@ def main():
             scores[b][:, :n_local].copy_(compact)
         if events:
             events[1].record()
-        if world > 1:
+        if comm:
             if backend == "nccl":
                 pending[b] = dist.gather(scores[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
             else:  # gloo rehearsal of the control flow: staged through host tensors
@@ -306,7 +314,7 @@ def main():
                 pending[b].wait()
                 pending[b] = None
         torch.cuda.synchronize()
-        if world > 1:
+        if comm:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -319,7 +327,7 @@ def main():
         step(a.warmup + i, ev[i])
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1 and os.environ.get("MTK_BENCH_CHECK"):  # rehearsal: every rank's block arrived at the consumer, in rank order
+    if comm and (os.environ.get("MTK_BENCH_CHECK") or a.rehearse_rccl):  # rehearsal: every rank's block arrived at the consumer, in rank order
         last = (a.warmup + a.steps - 1) % nbuf
         mine = scores[last].flatten()[:4].cpu()
         every = [torch.empty_like(mine) for _ in range(world)]
@@ -328,7 +336,7 @@ def main():
             assert torch.equal(gathered[last][0], scores[last])
             for r in range(world):
                 assert torch.equal(gathered[last][r].flatten()[:4].cpu(), every[r].cpu()), r
-    if world > 1:
+    if comm:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -384,8 +392,8 @@ def main():
     extras = {}
     if not a.no_extras and not strong:
         # the other half of the metric, on every rank (independent chains, no collective in the loop)
-        extras["sampling_4x512"] = bench_sampling(mtk, dev, 512, a.sample_rows, dist, world)
-        extras["sampling_4x1024"] = bench_sampling(mtk, dev, 1024, a.sample_rows, dist, world)
+        extras["sampling_4x512"] = bench_sampling(mtk, dev, 512, a.sample_rows, dist, world, comm)
+        extras["sampling_4x1024"] = bench_sampling(mtk, dev, 1024, a.sample_rows, dist, world, comm)
         out["sampled_rows_per_s"] = extras["sampling_4x1024"]["sampled_rows_per_s"]  # BASELINE configs[3]: 4x1024, shape M, T = 1000
         out["sampled_rows_per_s_4x512"] = extras["sampling_4x512"]["sampled_rows_per_s"]
     if not a.no_extras and world == 1 and not strong:
@@ -409,7 +417,10 @@ def main():
         out["extra"] = extras
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if comm:
+        if rank == 0 and a.rehearse_rccl:
+            out_note = {"rehearse_rccl": "ok: nccl process group of %d rank(s); async double-buffered gather, barriers and MAX all-reduce ran" % world}
+            print(json.dumps(out_note), file=sys.stderr, flush=True)
         dist.destroy_process_group()
 
 

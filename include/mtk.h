@@ -107,6 +107,11 @@ int mtk_ctx_reserve(mtk_ctx* ctx, int64_t max_rows, mtk_stream stream);
  * Philox seed and first global row from the device pair {seed, row0} at seed_row0_dev instead of from their arguments (NULL:
  * back to the arguments) - a captured chain is replayed with new noise by rewriting 16 bytes. */
 int mtk_ctx_set_seed_source(mtk_ctx* ctx, const uint64_t* seed_row0_dev);
+/* No reference counterpart: a counter that moves whenever the context frees or (re)allocates a device buffer its kernels are
+ * handed - an activation workspace growing for a larger call (or through mtk_ctx_reserve), the weight images being rebuilt by
+ * mtk_mlp_set_weights.  A HIP graph captured from this context's entry points holds raw addresses of those buffers: its owner
+ * records the value at capture time and re-captures (never replays) once it differs.  -1 for a null context. */
+int64_t mtk_ctx_workspace_generation(mtk_ctx* ctx);
 
 /* MODEL:583-585, 610-612 (IsTargetConditioned.EMBEDDING with num_classes > 0): the denoiser adds
  * silu(label_embedding.weight[y]) to the time embedding of every record.  Here a (label, timestep) pair is ONE row of the

@@ -82,6 +82,8 @@ extern "C" int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K
     return MTK_OK;
 }
 
+extern "C" int64_t mtk_ctx_workspace_generation(mtk_ctx* c) { return c ? (int64_t)c->ws_gen : -1; }
+
 extern "C" void mtk_ctx_destroy(mtk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

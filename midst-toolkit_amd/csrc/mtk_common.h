@@ -97,6 +97,10 @@ struct mtk_ctx {
     double* d_kl = nullptr;  // [T][4]: posterior_mean_coef1/2, posterior_log_variance_clipped, model log-variance (KL Gaussian loss; built on first use)
     const uint64_t* seed_src = nullptr;  // device {seed, row0} read by the reverse-chain kernels instead of their arguments (graph replay)
     int64_t reserved_rows = 0;           // mtk_ctx_reserve: workspaces stay sized for calls of up to this many rows
+    // Bumped whenever a context-owned device buffer that kernels are handed is freed or (re)allocated: activation workspaces
+    // growing, the packed weight images being rebuilt.  A captured HIP graph holds raw addresses of those buffers; its owner
+    // compares mtk_ctx_workspace_generation() with the value at capture time and re-captures when it moved.
+    uint64_t ws_gen = 0;
     bool fast_math = false;  // MTK_MATH_FAST: diffusion kernels on hardware transcendentals, exact block LSE
     // denoiser
     bool have_weights = false;

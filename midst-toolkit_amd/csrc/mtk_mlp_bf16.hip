@@ -931,6 +931,7 @@ int mtk_reserve_fused_tf(mtk_ctx* c, int64_t records, hipStream_t s) {
     c->tf_pack_elems = 0;
     MTK_HIP(hipMalloc(&c->tf_pack, sizeof(float) * need));
     c->tf_pack_elems = need;
+    ++c->ws_gen;
     return MTK_OK;
 }
 

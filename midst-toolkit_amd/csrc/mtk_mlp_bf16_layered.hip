@@ -659,6 +659,7 @@ int ensure_ws16(mtk_ctx* c, int64_t B, bool split, hipStream_t s) {
         MTK_HIP(hipMalloc(&c->ws16[i], sizeof(uint16_t) * need));
     }
     c->ws16_elems = need;
+    ++c->ws_gen;
     return MTK_OK;
 }
 

@@ -214,6 +214,7 @@ int launch_gemm(const GemmArgs& g, int64_t Mpad, int Npad, hipStream_t s) {
 }  // namespace
 
 void mtk_free_mlp(mtk_ctx* c) {
+    ++c->ws_gen;
     free_layer(c->proj);
     free_layer(c->temb0);
     free_layer(c->temb2);
@@ -393,6 +394,7 @@ static int ensure_ws_f32(mtk_ctx* c, int64_t B, hipStream_t s) {
         MTK_HIP(hipMalloc(&c->ws[i], sizeof(float) * need));
     }
     c->ws_elems = need;
+    ++c->ws_gen;
     return MTK_OK;
 }
 

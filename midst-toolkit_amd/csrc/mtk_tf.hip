@@ -52,6 +52,7 @@ int ensure_tf_ws(mtk_ctx* c, int64_t rows, hipStream_t s) {
         MTK_HIP(hipMalloc(&c->tf_ws[i], sizeof(float) * need));
     }
     c->tf_ws_elems = need;
+    ++c->ws_gen;
     return MTK_OK;
 }
 

@@ -433,6 +433,7 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     if (Mpad <= tr.cap) return MTK_OK;
     MTK_HIP(hipStreamSynchronize(s));
     free_acts(tr);
+    ++c->ws_gen;
     const int Dp = round_up(c->D, 128);
     int maxpad = c->proj.out_pad;
     for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
@@ -447,8 +448,12 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     // split-K slabs of the weight-gradient GEMMs (deterministic reductions): every layer has its own region (splits x
     // layer), so that ONE reduction kernel at the end of the backward pass adds all of them
     size_t need = 0, need_rs = 0;
+    // splits_for is not monotonic in K (the chunk is rounded up to TK, so a slightly SMALLER batch can need one more split):
+    // size for the most splits any batch up to the capacity can ask for, ceil(512 / tiles) (kchunk_for's target)
     auto account = [&](const MlpLayer& l, int64_t K) {
-        const int sp = splits_for(K, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
+        const int tiles = (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN);
+        const int sp_k = splits_for(K, tiles), sp_max = (512 + tiles - 1) / tiles;
+        const int sp = sp_k > sp_max ? sp_k : sp_max;
         need += (size_t)sp * l.out_pad * l.in_pad;
         need_rs += (size_t)sp * l.out_pad;
     };

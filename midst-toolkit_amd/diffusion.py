@@ -314,7 +314,14 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         if getattr(eng, "_train_state", None) is None:
             net.sync_weights()  # layer shapes and current weights into the context, then the [5, n] image on top
             eng.train_attach(timestep_frequencies(net.timestep_dimension))
+            eng._image_owner = "autograd"
             self._ag_key = key
+        elif getattr(eng, "_image_owner", None) == "trainer":
+            # A ClavaDDPMTrainer trains on this context: image 0 IS the model (the nn.Parameters are only refreshed by
+            # sync_modules, so they usually still hold the initial weights).  A differentiable mixed_loss between trainer steps
+            # - a validation loss computed without torch.no_grad() - evaluates those live weights and leaves them alone;
+            # importing the stale parameters here would silently reset the run while Adam's moments and the EMA carried on.
+            pass
         elif key != getattr(self, "_ag_key", None):  # an optimizer step (or a load) changed the parameters
             eng.train_import("weights", [(W.data, b.data) for W, b in net._weights()])
             self._ag_key = key
@@ -467,13 +474,26 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         launches - as ONE HIP graph (GMD:1403-1417 is a Python loop of T iterations in the reference).  In-kernel Philox noise
         only: no host draw happens inside the loop, and the kernels read {seed, row0} from a 16-byte device buffer
         (mtk_ctx_set_seed_source), so one captured graph serves every later call with the same batch size and weights.
-        Captured once per (batch size, packed weights, precision, math) after mtk_ctx_reserve has sized the workspaces;
+        Captured once per (batch size, packed weights, precision, math) after mtk_ctx_reserve has sized the workspaces, and again
+        whenever the context has reallocated a workspace since (mtk_ctx_workspace_generation);
         replays allocate nothing and make one launch call.  Same kernels and arguments as the eager loop: same samples."""
         dev = eng.device
         Nn, C, D, T = eng.Nn, eng.C, eng.D, self.num_timesteps
         key = (B, str(dev), self.precision, self.math, getattr(self._denoise_fn, "_synced_key", None), id(eng))
         cache = self.__dict__.setdefault("_graphs", {})
+
+        def generation():
+            # the captured launches hold raw addresses of the contexts' workspaces: a call with more rows than were reserved
+            # (eager or a capture at another batch size) reallocates them, and the counter says so
+            gens = [eng.workspace_generation()]
+            if self._label_net():
+                gens.append(self._denoise_fn.engine(dev).workspace_generation())
+            return tuple(gens)
+
         ent = cache.get(key)
+        if ent is not None and ent["generation"] != generation():
+            cache.pop(key)  # stale: replaying it would read and write freed device memory
+            ent = None
         if ent is None:
             while len(cache) >= 4:  # static buffers per entry: keep a few batch sizes
                 cache.pop(next(iter(cache)))
@@ -504,14 +524,17 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             finally:
                 eng.set_seed_source(None)
             ent["graph"] = graph
+            ent["generation"] = generation()
             cache[key] = ent
         ent["seed"].copy_(torch.tensor([seed, row0], dtype=torch.int64))
         ent["graph"].replay()
         return ent["sample"].clone()
 
-    def _target_fn(self, batch_size: int, target_dist: Tensor, inj: dict | None):
+    def _target_fn(self, batch_size: int, target_dist: Tensor, inj: dict | None, targets: Tensor | None = None):
         def draw():
-            if inj is not None and "y" in inj:
+            if targets is not None:  # labels decided by the caller (sharded sampling: one global draw, distributed.shared_labels)
+                target = targets
+            elif inj is not None and "y" in inj:
                 target = inj["y"]
             else:
                 target = torch.multinomial(target_dist, num_samples=batch_size, replacement=True)
@@ -521,19 +544,22 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
 
     @torch.no_grad()
     def sample(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
-               conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+               conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None,
+               _targets: Tensor | None = None) -> tuple[Tensor, dict[str, Tensor]]:
         """GMD:1370.  Returns ([B, Nn + C] fp64 on CPU, {"y": labels}).  ``conditioning_function``: classifier guidance
         of the numeric features (gaussian_p_sample GMD:699-702).  ``row0`` / ``seed`` (not in the reference): Philox
-        stream position of row 0 and the shared seed, for sharded sampling."""
-        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected), model_kwargs, conditioning_function,
+        stream position of row 0 and the shared seed, for sharded sampling; ``_targets``: the batch's labels, when the
+        caller has drawn them (instead of ``torch.multinomial(target_dist)`` here)."""
+        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected, _targets), model_kwargs, conditioning_function,
                                    _injected, row0=row0, seed=seed)
 
     @torch.no_grad()
     def sample_ddim(self, batch_size: int, target_dist: Tensor, model_kwargs: dict[str, Any] | None = None,
-                    conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None) -> tuple[Tensor, dict[str, Tensor]]:
+                    conditioning_function=None, _injected: dict | None = None, row0: int = 0, seed: int | None = None,
+                    _targets: Tensor | None = None) -> tuple[Tensor, dict[str, Tensor]]:
         """GMD:1259 (eta = 0).  Returns ([B, Nn + C] fp32 on CPU, {"y": labels}).  ``conditioning_function``: score-based
         guidance of the numeric features (condition_score, GMD:617-661)."""
-        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected), model_kwargs, conditioning_function,
+        return self._reverse_chain(batch_size, self._target_fn(batch_size, target_dist, _injected, _targets), model_kwargs, conditioning_function,
                                    _injected, ddim=True, row0=row0, seed=seed)
 
     @torch.no_grad()
@@ -597,15 +623,22 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
 
     def sample_all(self, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False,
                    model_kwargs: dict[str, Any] | None = None, conditioning_function=None, row0: int = 0,
-                   seed: int | None = None) -> tuple[Tensor, Tensor]:
+                   seed: int | None = None, _targets: Tensor | None = None) -> tuple[Tensor, Tensor]:
         """GMD:1426.  ``row0`` / ``seed`` (not in the reference): see ``sample``; batch i of this call continues the
-        Philox row range at ``row0 + i * batch_size``."""
+        Philox row range at ``row0 + i * batch_size``.  ``_targets`` [num_samples]: the labels of this call's rows when the
+        caller has drawn them (sharded sampling); a last batch that runs past them repeats the final label for the rows
+        that are cut off anyway."""
         all_targets, all_samples = [], []
         num_generated = 0
         while num_generated < num_samples:
             sample_fn = self.sample_ddim if ddim else self.sample  # GMD:1452-1455
+            tb = None
+            if _targets is not None:
+                tb = _targets[num_generated:num_generated + batch_size].long()
+                if tb.shape[0] < batch_size:
+                    tb = torch.cat([tb, tb[-1:].expand(batch_size - tb.shape[0])])
             sample, outputs = sample_fn(batch_size, target_dist, model_kwargs=model_kwargs, conditioning_function=conditioning_function,
-                                        row0=row0 + num_generated, seed=seed)
+                                        row0=row0 + num_generated, seed=seed, _targets=tb)
             mask_nan = torch.any(sample.isnan(), dim=1)
             sample = sample[~mask_nan]
             outputs["y"] = outputs["y"].to(sample.device)[~mask_nan]

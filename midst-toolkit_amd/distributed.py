@@ -5,6 +5,8 @@ Works on any ``torch.distributed`` backend: ``nccl`` (= RCCL over xGMI) on the G
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import Tensor
@@ -26,11 +28,12 @@ def shard_range(n: int, rank: int, world_size: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_rows(local: Tensor, n_total: int, dim: int = 0) -> Tensor:
+def gather_rows(local: Tensor, n_total: int, dim: int = 0, force_collective: bool = False) -> Tensor:
     """All-gather blocks that were split with :func:`shard_range` along ``dim`` back into global order.
-    Equal blocks go through one ``all_gather_into_tensor``; ragged ones are padded to the largest block."""
+    Equal blocks go through one ``all_gather_into_tensor``; ragged ones are padded to the largest block.
+    ``force_collective``: go through the collective even at world size 1 (the one-GPU rehearsal of the RCCL path)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return local
     local = local.movedim(dim, 0).contiguous()
     sizes = [shard_range(n_total, r, ws)[1] - shard_range(n_total, r, ws)[0] for r in range(ws)]
@@ -48,7 +51,7 @@ def gather_rows(local: Tensor, n_total: int, dim: int = 0) -> Tensor:
 
 @torch.no_grad()
 def score_records_sharded(diffusion_model, features: Tensor, noise: Tensor, timesteps, additional_timestep: int = 0,
-                          precision: str | None = None) -> Tensor:
+                          precision: str | None = None, force_collective: bool = False) -> Tensor:
     """:func:`scoring.score_records` over all ranks: every rank passes the SAME ``features`` ([N, .], host or device),
     scores its contiguous block on its GPU and receives the full [n_t, N, P] score tensor."""
     from .scoring import score_records
@@ -57,33 +60,61 @@ def score_records_sharded(diffusion_model, features: Tensor, noise: Tensor, time
     lo, hi = shard_range(features.shape[0], rank, ws)
     dev = diffusion_model.alphas.device
     local = score_records(diffusion_model, features[lo:hi].to(dev), noise, timesteps, additional_timestep, precision)
-    return gather_rows(local, features.shape[0], dim=1)
+    return gather_rows(local, features.shape[0], dim=1, force_collective=force_collective)
 
 
-def shared_seed() -> int:
+def _comm_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def shared_seed(force_collective: bool = False) -> int:
     """One 62-bit seed that every rank agrees on: drawn on rank 0 from torch's CPU generator and broadcast."""
     rank, ws = world()
     seed = torch.randint(1, 2**62, (1,), dtype=torch.int64)
-    if ws > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        seed = seed.to(dev)
+    if ws > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
+        seed = seed.to(_comm_device())
         dist.broadcast(seed, src=0)
     return int(seed.item())
 
 
-def sample_all_sharded(diffusion_model, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False):
+def shared_labels(num_samples: int, batch_size: int, target_dist: Tensor, force_collective: bool = False) -> Tensor:
+    """The labels ``sample_all(num_samples, batch_size, target_dist)`` draws on one device (GMD:1401 per batch: one
+    ``torch.multinomial`` of ``batch_size`` labels, the batches concatenated and cut to ``num_samples``), drawn on rank 0 from
+    ITS generator and broadcast: label r belongs to global row r, so the gathered labels - like the rows - do not depend on the
+    number of GPUs.  (Drawn per rank instead, identically seeded processes - the reference pipeline's habit - would all draw
+    the same sequence, and the gathered vector would hold world_size copies of it.)"""
+    rank, ws = world()
+    n_batches = -(-num_samples // batch_size) if num_samples > 0 else 0
+    if rank == 0:
+        parts = [torch.multinomial(target_dist, num_samples=batch_size, replacement=True) for _ in range(n_batches)]
+        y = (torch.cat(parts) if parts else torch.empty((0,), dtype=torch.long))[:num_samples].long()
+    else:
+        y = torch.empty((num_samples,), dtype=torch.long)
+    if ws > 1 or (force_collective and dist.is_available() and dist.is_initialized()):
+        y = y.to(_comm_device())
+        dist.broadcast(y, src=0)
+    return y.cpu()
+
+
+def sample_all_sharded(diffusion_model, num_samples: int, batch_size: int, target_dist: Tensor, ddim: bool = False,
+                       force_collective: bool = False):
     """``sample_all`` (GMD:1426) with the rows split over ranks; each rank runs its own T-loop, the only exchange is
     the final gather of the [N, Nn + C] samples and their labels.
 
     The reference pipeline seeds every process identically (common/random.py:11-55), so the ranks must be decorrelated
     here, not by the caller: with ``rng="philox"`` all ranks share ONE seed (broadcast from rank 0) and rank r's rows
-    take the Philox row range [lo_r, hi_r) - the samples do not depend on the number of GPUs; with ``rng="torch"`` each
+    take the Philox row range [lo_r, hi_r), and the labels of all rows are drawn once on rank 0 (:func:`shared_labels`) - samples
+    and labels do not depend on the number of GPUs; with ``rng="torch"`` each
     rank re-seeds torch's generators inside a fork with (a seed drawn from the caller's generator) + rank, and the
     caller's generator state is restored on return.  An empty shard contributes zero rows."""
     rank, ws = world()
+    comm = ws > 1 or (force_collective and dist.is_available() and dist.is_initialized())
     lo, hi = shard_range(num_samples, rank, ws)
     if diffusion_model.rng == "philox":
-        x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim, row0=lo, seed=shared_seed())
+        seed = shared_seed(force_collective)
+        labels = shared_labels(num_samples, batch_size, target_dist, force_collective) if comm else None
+        x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim, row0=lo, seed=seed,
+                                          _targets=labels[lo:hi] if labels is not None else None)
     elif ws == 1:
         x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim)
     else:
@@ -92,10 +123,11 @@ def sample_all_sharded(diffusion_model, num_samples: int, batch_size: int, targe
         with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else []):
             torch.manual_seed(base + rank)
             x, y = diffusion_model.sample_all(hi - lo, batch_size, target_dist, ddim=ddim)
-    if ws == 1:
+    if not comm:
         return x, y
     dev = diffusion_model.alphas.device if dist.get_backend() == "nccl" else torch.device("cpu")
-    return gather_rows(x.to(dev), num_samples).cpu(), gather_rows(y.to(dev), num_samples).cpu()
+    return (gather_rows(x.to(dev), num_samples, force_collective=force_collective).cpu(),
+            gather_rows(y.to(dev), num_samples, force_collective=force_collective).cpu())
 
 
 def allreduce_gradients(grad_image: Tensor) -> None:
@@ -116,11 +148,20 @@ class BucketedGradientExchange:
 
     On a CPU image or with the gloo backend (tests; two ranks sharing one GPU) the same bucket loop runs blocking."""
 
-    def __init__(self, engine, grad_image: Tensor, layout: list[tuple[int, int]] | None = None):
+    def __init__(self, engine, grad_image: Tensor, layout: list[tuple[int, int]] | None = None, overlapped: bool | None = None):
+        """``overlapped``: None = overlap whenever it applies (more than one rank, RCCL, a device image) unless the environment
+        says ``MTK_DP_OVERLAP=0`` (the switch back to the blocking per-bucket all-reduce); True = also at world size 1 (the
+        one-GPU rehearsal of the side-stream path); False = blocking."""
         self.image = grad_image
         self.layout = layout if layout is not None else (engine.train_bucket_layout() if engine is not None else [(0, grad_image.numel())])
         self.world = world()[1]
-        self.overlapped = bool(self.world > 1 and grad_image.is_cuda and dist.get_backend() == "nccl")
+        can = bool(grad_image.is_cuda and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and engine is not None)
+        if overlapped is None:
+            overlapped = self.world > 1 and os.environ.get("MTK_DP_OVERLAP", "1") != "0"
+        elif overlapped and not can:
+            raise RuntimeError("BucketedGradientExchange(overlapped=True) needs an initialised nccl (RCCL) process group and a device image")
+        self.overlapped = bool(overlapped and can)
+        self.forced = bool(self.overlapped and self.world == 1)
         self.engine = engine
         self.events = None
         self.stream = None
@@ -130,7 +171,7 @@ class BucketedGradientExchange:
             self.stream = torch.cuda.Stream(device=grad_image.device)
 
     def launch(self) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self.forced:
             return
         if not self.overlapped:
             if self.image.is_cuda:

@@ -75,6 +75,11 @@ class Engine:
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_ctx_reserve(self._h, int(max_rows), self._stream()))
 
+    def workspace_generation(self) -> int:
+        """Moves whenever the context frees / reallocates a buffer its kernels use (mtk_ctx_workspace_generation): a captured
+        graph is only valid while this equals its value at capture time."""
+        return int(_lib.lib().mtk_ctx_workspace_generation(self._h))
+
     def set_seed_source(self, seed_row0: torch.Tensor | None) -> None:
         """``seed_row0``: int64 [2] device tensor {seed, row0} the reverse-chain kernels read instead of their arguments."""
         if seed_row0 is not None:
@@ -100,6 +105,7 @@ class Engine:
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_mlp_set_weights(self._h, n_hidden, d.ctypes.data, Wp, bp, f.ctypes.data, self._stream()))
         self._train_state = None  # setting weights detaches a training image
+        self._image_owner = None
 
     def set_label_embedding(self, weight: torch.Tensor | None, period: int = 0) -> None:
         """MODEL:610-612 as table rows (mtk_mlp_set_label_embedding): call before set_weights; None clears."""
@@ -230,6 +236,7 @@ class Engine:
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_train_attach(self._h, ptr(state), f.ctypes.data, self._stream()))
         self._train_state = state  # keeps the buffer alive while the context reads weights from it
+        self._image_owner = None   # who writes image 0: "trainer" (ClavaDDPMTrainer) or "autograd" (the mixed_loss seam)
         return state
 
     def train_step(self, x0, t, eps, u, inv_global_batch, loss_multi=None, loss_gauss=None, seed=0, row0=0) -> None:

@@ -60,11 +60,25 @@ class ClavaDDPMTrainer:
         if getattr(net, "precision", "fp32") != "fp32" or diffusion_model.precision != "fp32":
             raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
         self._engine = diffusion_model.engine()
+        if getattr(self._engine, "_train_state", None) is not None:
+            # the autograd seam of mixed_loss (or an earlier trainer) left a training image on this context: write its weights
+            # back into the module and re-pack, so that this trainer starts from them with fresh optimizer state
+            self._engine.train_export("weights", self._tensors(net))
+            net._synced_key = None
+            self._engine = diffusion_model.engine()
         self.state = self._engine.train_attach(timestep_frequencies(net.timestep_dimension))
+        self._engine._image_owner = "trainer"  # image 0 is the live model from here on: the autograd seam must not overwrite it
         self._engine.train_set_gaussian_loss(getattr(diffusion_model.gaussian_loss_type, "value", "mse"))  # GMD:534
         self._rank, self._world = world()
         # data parallel: one all-reduce per gradient bucket, issued under the backward (distributed.BucketedGradientExchange)
         self._exchange = BucketedGradientExchange(self._engine, self.state[1]) if self._world > 1 else None
+
+    def use_exchange(self, overlapped: bool | None = None) -> None:
+        """(Re)build the gradient exchange: ``overlapped=True`` runs the side-stream, per-bucket RCCL all-reduce even at world
+        size 1 (how the path is rehearsed on a one-GPU box); ``False`` is the blocking per-bucket form; ``None`` the default."""
+        if self._exchange is not None:
+            self._exchange.close()
+        self._exchange = BucketedGradientExchange(self._engine, self.state[1], overlapped=overlapped)
 
     # ------------------------------------------------------------------ TRAINER:58
     def _anneal_learning_rate(self, step: int) -> None:

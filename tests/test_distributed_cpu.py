@@ -141,10 +141,14 @@ class _FakeSampler:
         self.alphas = torch.zeros(1)
         self.calls = []
 
-    def sample_all(self, num_samples, batch_size, target_dist, ddim=False, row0=0, seed=None):
+    def sample_all(self, num_samples, batch_size, target_dist, ddim=False, row0=0, seed=None, _targets=None):
         self.calls.append((num_samples, batch_size, row0, seed))
         if num_samples == 0:
             return torch.empty((0, 3), dtype=torch.float64), torch.empty((0,), dtype=torch.long)
+        if _targets is not None:  # the caller's labels, one per row of this call (GaussianMultinomialDiffusion.sample_all does the same)
+            assert _targets.shape == (num_samples,)
+            rows = torch.arange(row0, row0 + num_samples, dtype=torch.float64)
+            return torch.stack([rows, torch.full_like(rows, float(seed % 1000)), (rows * 7 + seed % 13) % 5], 1), _targets.long()
         if self.rng == "philox":
             rows = torch.arange(row0, row0 + num_samples, dtype=torch.float64)
             x = torch.stack([rows, torch.full_like(rows, float(seed % 1000)), (rows * 7 + seed % 13) % 5], 1)
@@ -175,8 +179,17 @@ def test_sample_all_sharded_philox_rows_do_not_depend_on_world_size(n):
     torch.manual_seed(1234)
     import midst_toolkit_amd.distributed as D
 
-    single, _ = D.sample_all_sharded(_FakeSampler("philox"), n, 16, torch.ones(4))
+    single, y_single = D.sample_all_sharded(_FakeSampler("philox"), n, 16, torch.ones(4))
     assert torch.equal(single, x0)
+    # the labels too: drawn once on rank 0 for the global row range, batch by batch as one process draws them - not one
+    # identical sequence per identically seeded rank (which would gather into world_size copies of the same draws)
+    torch.manual_seed(1234)
+    torch.randint(1, 2**62, (1,), dtype=torch.int64)  # shared_seed()'s draw
+    want = torch.cat([torch.multinomial(torch.ones(4), 16, replacement=True) for _ in range(-(-n // 16))])[:n]
+    assert torch.equal(y0, want)
+    if n > 8:
+        h = (n + 1) // 2
+        assert not torch.equal(y0[: n - h], y0[h:]), "the two shards' labels must not be copies of each other"
 
 
 def test_sample_all_sharded_torch_rng_decorrelates_identically_seeded_ranks():

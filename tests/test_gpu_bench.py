@@ -63,3 +63,16 @@ def test_bench_two_rank_strong_scaling_rehearsal():
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["noise_draws"] == 4
     assert out["config"]["evals_per_step"] == 8191 * 3 * 4
+
+
+def test_bench_rccl_single_rank_rehearsal():
+    """The N > 1 loop of bench.py on REAL RCCL, as far as one GPU allows: an nccl process group of one rank, device_id bound,
+    the asynchronous double-buffered dist.gather of every step's score block, the barriers and the MAX all-reduce of the time
+    (gloo cannot show that the RCCL calls and their stream semantics work; two ranks cannot share a card under RCCL)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "bench.py", "--rehearse-rccl", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "70",
+                        "--no-cpu-baseline", "--sample-rows", "1024"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _last_json(r.stdout)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["sampled_rows_per_s"] > 0
+    assert "rehearse_rccl" in r.stderr

@@ -1459,6 +1459,44 @@ def test_graph_replayed_chain_equals_eager_chain(tag, precision):
     assert torch.equal(x2, x)
 
 
+@pytest.mark.parametrize("tag,precision", [("B_ragged", "fp32"), ("M_mixed", "bf16x3"), ("B_ragged", "bf16")])  # bf16 at 2x128: the layered path
+def test_cached_chain_graph_survives_workspace_growth(tag, precision):
+    """A captured chain holds raw addresses of the context's activation workspaces.  A later call with more rows than were
+    reserved (an eager forward, or a capture at a second batch size) frees and reallocates them: the cached graph must be
+    re-captured (mtk_ctx_workspace_generation), not replayed into freed memory."""
+    c = load_case(tag)
+    d = build(c, precision=precision, T=40)
+    d.rng = "philox"
+    B1, B2 = 300, 5000
+    eager1, _ = d.sample(B1, torch.ones(1), seed=21, row0=0)
+    eager2, _ = d.sample(B2, torch.ones(1), seed=22, row0=0)
+    d2 = build(c, precision=precision, T=40)   # fresh context: workspaces start small
+    d2.rng, d2.use_graph = "philox", True
+    g1, _ = d2.sample(B1, torch.ones(1), seed=21, row0=0)
+    gen1 = d2.engine().workspace_generation()
+    assert torch.equal(g1, eager1)
+    # an eager denoiser call with more rows than the capture reserved moves the workspaces
+    eng = d2.engine()
+    x = torch.randn((B2, eng.D), device=dev())
+    eng.mlp_forward(x, torch.zeros((B2,), dtype=torch.int64, device=dev()), precision=precision)
+    assert d2.engine().workspace_generation() != gen1
+    # whatever reuses the freed blocks must not be touched by the replay either
+    junk = [torch.full((1 << 20,), float("nan"), device=dev()) for _ in range(8)]
+    g1b, _ = d2.sample(B1, torch.ones(1), seed=21, row0=0)
+    assert torch.equal(g1b, eager1)
+    assert all(bool(torch.isnan(j).all()) for j in junk)
+    # a second cached batch size grows the reservation; the first entry is refreshed on its next use, both stay cached
+    g2, _ = d2.sample(B2, torch.ones(1), seed=22, row0=0)
+    g1c, _ = d2.sample(B1, torch.ones(1), seed=21, row0=0)
+    g2b, _ = d2.sample(B2, torch.ones(1), seed=22, row0=0)
+    assert torch.equal(g2, eager2) and torch.equal(g1c, eager1) and torch.equal(g2b, eager2)
+    assert len(d2._graphs) == 2
+    gen = d2.engine().workspace_generation()
+    d2.sample(B1, torch.ones(1), seed=23, row0=0)
+    d2.sample(B2, torch.ones(1), seed=23, row0=0)
+    assert d2.engine().workspace_generation() == gen   # steady state: no reallocation, no re-capture
+
+
 def test_attack_feature_driver_reproduces_the_reference_loop():
     """AttackFeatureDriver against the loop it replaces: for each model, for each timestep, for each
     additional timestep, mixed_loss(...) -> x[:, count * P:(count + 1) * P] (TF:531-549).  Same kernels: identical features;

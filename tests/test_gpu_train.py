@@ -547,6 +547,160 @@ def test_two_rank_sharded_sampling_equals_the_single_device_rows():
     assert res[0] == ((301, 11), True, 0) and res[1] == ((301, 11), True, 0), res
 
 
+def _rccl_one_rank_body(q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    res = {}
+    try:
+        import midst_toolkit_amd as mtk
+        import midst_toolkit_amd.distributed as D
+        from midst_toolkit_amd import scoring
+
+        # 1. training: the side-stream, per-bucket all-reduce under the backward, over consecutive iterations (the next
+        #    iteration's memset of the gradient image and its kernels must order behind the exchange), against the single
+        #    blocking all-reduce and against no exchange at all: at one rank every sum is the identity, so all three runs
+        #    must agree bit for bit in gradients and in the weights after every AdamW step
+        c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[256, 128, 128])
+        p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+        batches = [[v.to(dev()) for v in big_batch(c, 1536, seed=10 + i)] for i in range(6)]
+
+        def run(mode):
+            tr, d = build_trainer(c, p0, steps=len(batches))
+            if mode == "overlapped":
+                tr.use_exchange(True)
+                assert tr._exchange.overlapped and tr._exchange.forced and tr._exchange.stream is not None
+            snaps = []
+            for i, (x0, t, eps, u) in enumerate(batches):
+                if mode == "blocking":
+                    tr._engine.train_step(x0, t, eps, u, 1.0 / x0.shape[0], None, None)
+                    dist.all_reduce(tr.state[1])
+                    g = tr.optimizer.param_groups[0]
+                    tr.optimizer.steps_done += 1
+                    tr._engine.train_apply(g["lr"], g["weight_decay"], tr.optimizer.steps_done, g["betas"], g["eps"], tr.ema_rate)
+                else:
+                    tr._train_step(x0, injected=(t, eps, u))
+                tr._anneal_learning_rate(i)
+                snaps.append((tr.state[1].clone(), tr.state[0].clone()))
+            torch.cuda.synchronize()
+            if tr._exchange is not None:
+                tr._exchange.close()
+            return snaps
+
+        plain, blocking, over = run("none"), run("blocking"), run("overlapped")
+        res["train_blocking"] = all(bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) for a, b in zip(plain, blocking))
+        res["train_overlapped"] = all(bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) for a, b in zip(plain, over))
+        res["train_moved"] = not bool(torch.equal(plain[0][1], plain[-1][1]))
+
+        # 2. gather_rows through all_gather_into_tensor (device tensors, RCCL), along both dims
+        x = torch.randn((257, 5), device=dev())
+        res["gather"] = bool(torch.equal(D.gather_rows(x, 257, force_collective=True), x)
+                             and torch.equal(D.gather_rows(x.t().contiguous(), 257, dim=1, force_collective=True), x.t()))
+
+        # 3. sharded sampling: seed and labels broadcast over RCCL, rows and labels gathered; equal to the plain call
+        K, Nn, T, N = np.asarray([3, 7, 10, 2, 12]), 6, 12, 301
+        torch.manual_seed(0)
+        net = mtk.MLPDiffusion(Nn + int(K.sum()), 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+        d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev()).to(dev())
+        d.rng = "philox"
+        td = torch.tensor([0.2, 0.5, 0.3])
+        torch.manual_seed(1234)
+        xs, ys = D.sample_all_sharded(d, N, 128, td, force_collective=True)
+        torch.manual_seed(1234)
+        seed = int(torch.randint(1, 2**62, (1,), dtype=torch.int64).item())
+        full, yf = d.sample_all(N, 128, td, row0=0, seed=seed)
+        res["sampling"] = (tuple(xs.shape), bool(torch.equal(xs, full)), bool(torch.equal(ys.cpu(), yf.cpu())), int(ys.max()) > 0)
+
+        # 4. sharded scoring: blocks gathered along the record axis
+        torch.manual_seed(0)
+        netn = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+        dn = mtk.GaussianMultinomialDiffusion(np.asarray([0]), Nn, netn, num_timesteps=50, device=dev()).to(dev())
+        feats, noise = torch.randn((333, Nn)), torch.randn((3, Nn))
+        got = D.score_records_sharded(dn, feats, noise, [1, 7, 30], force_collective=True)
+        want = scoring.score_records(dn, feats.to(dev()), noise, [1, 7, 30])
+        res["scoring"] = bool(torch.equal(got, want))
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_paths_on_a_single_rank_group():
+    """Every RCCL call of the multi-GPU path, executed once on hardware - as far as a one-GPU box allows: an nccl
+    process group of ONE rank.  The overlapped gradient exchange (side stream, per-bucket wait_event + all_reduce, wait_stream
+    before the optimizer) is forced on and must leave gradients and weights bit-identical to the blocking all-reduce and to no
+    exchange over six consecutive iterations; gather_rows, sample_all_sharded (seed + label broadcast, row gather) and
+    score_records_sharded go through their collectives and must equal the single-process results."""
+    import os
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_rccl_one_rank_body, args=(q,))
+    p.start()
+    p.join(240)
+    assert p.exitcode == 0, p.exitcode
+    res = q.get()
+    assert res["train_blocking"] and res["train_overlapped"] and res["train_moved"], res
+    assert res["gather"] and res["scoring"], res
+    assert res["sampling"] == ((301, 11), True, True, True), res
+
+
+def test_autograd_seam_leaves_a_trainers_image_alone():
+    """A differentiable mixed_loss between trainer steps (a validation loss computed without torch.no_grad(), as loops written
+    for the reference do) shares the trainer's context.  It must evaluate the LIVE weights of image 0 and never import the
+    module's stale nn.Parameters over them (they are only refreshed by sync_modules)."""
+    c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[128, 128])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    tr, d = build_trainer(c, p0, steps=8)
+    batches = [[v.to(dev()) for v in big_batch(c, 512, seed=30 + i)] for i in range(4)]
+    for x0, t, eps, u in batches[:2]:
+        tr._train_step(x0, injected=(t, eps, u))
+    torch.cuda.synchronize()
+    w_before, m_before = tr.state[0].clone(), tr.state[2].clone()
+    initial = {k: v.detach().clone() for k, v in d._denoise_fn.state_dict().items()}
+    assert not torch.equal(w_before, tr.state[4])  # the image has moved away from the initial weights (EMA lags it)
+    x0 = batches[2][0]
+    torch.manual_seed(5)
+    lm, lg = d.mixed_loss(x0, {"y": torch.zeros(len(x0))})          # grad enabled: the autograd seam
+    assert lm.requires_grad or lg.requires_grad
+    (lm + lg).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.state[0], w_before) and torch.equal(tr.state[2], m_before)
+    # ... and it is the live model that was evaluated, not the module's initial parameters
+    torch.manual_seed(5)
+    with torch.no_grad():
+        lm2, lg2 = d.mixed_loss(x0, {"y": torch.zeros(len(x0))})
+    assert abs(float(lg) - float(lg2)) <= 1e-5 * abs(float(lg2)) + 1e-7
+    for k, v in d._denoise_fn.state_dict().items():
+        assert torch.equal(v, initial[k])                            # parameters untouched until sync_modules
+    x0, t, eps, u = batches[3]
+    tr._train_step(x0, injected=(t, eps, u))                         # training carries on from the same state
+    torch.cuda.synchronize()
+    assert not torch.equal(tr.state[0], w_before) and bool(torch.isfinite(tr.state[0]).all())
+
+
+def test_smaller_batch_after_the_capacity_batch_has_slab_room():
+    """The split-batch slabs are sized when the activations are: splits_for is not monotonic in the batch (8320 rows can
+    need fewer slices than 8192), so a smaller batch after the largest one must still fit."""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[512, 512])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    tr, d = build_trainer(c, p0)
+    for B in (8320, 8192, 4224, 640):
+        x0, t, eps, u = [v.to(dev()) for v in big_batch(c, B)]
+        tr._engine.train_step(x0, t, eps, u, 1.0 / B, None, None)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(tr.state[1]).all())
+
+
 @pytest.mark.parametrize("tag", ["B_ragged", "A_numeric"])
 def test_reference_trainer_loop_runs_against_the_drop_in(tag):
     """The reference's own training loop, statement for statement (TRAINER:39-51 set-up, :70-94 _train_step, :58-68 anneal,

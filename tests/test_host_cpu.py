@@ -150,3 +150,61 @@ def test_drop_in_objects_pickle_without_their_device_context():
     d3 = copy.deepcopy(d)
     assert d3._engine is None and d3._denoise_fn._engine is None
     assert d._engine is fake and net._engine is fake   # the live object keeps its context
+
+
+def test_integration_snippets_match_the_real_signatures():
+    """INTEGRATION.md section 2 is what a maintainer copies: every call it shows on the drop-in classes must bind to the real
+    signature (round 2 shipped an AttackFeatureDriver snippet with its arguments in the wrong order).  Each documented call is
+    parsed out of the file and bound with inspect.signature().bind - names, arity and keywords are checked, nothing runs."""
+    import ast
+    import inspect
+    import os
+    import re
+
+    import midst_toolkit_amd as mtk
+    from midst_toolkit_amd import distributed, scoring, tabsyn
+
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    block = re.search(r"## 2\..*?```python\n(.*?)```", text, re.S).group(1)
+    targets = {
+        "AttackFeatureDriver": mtk.AttackFeatureDriver.__init__, "drv.add_model": mtk.AttackFeatureDriver.add_model,
+        "drv.features": mtk.AttackFeatureDriver.features, "drv.matrix": mtk.AttackFeatureDriver.matrix,
+        "drv.challenge_predictions": mtk.AttackFeatureDriver.challenge_predictions,
+        "GaussianMultinomialDiffusion": mtk.GaussianMultinomialDiffusion.__init__,
+        "GaussianMultinomialDiffusion.from_reference_state": mtk.GaussianMultinomialDiffusion.from_reference_state.__func__,
+        "mixed_loss": scoring.mixed_loss, "diffusion.sample_all": mtk.GaussianMultinomialDiffusion.sample_all,
+        "diffusion.conditional_sample": mtk.GaussianMultinomialDiffusion.conditional_sample,
+        "diffusion.gaussian_ddim_sample": mtk.GaussianMultinomialDiffusion.gaussian_ddim_sample,
+        "diffusion.gaussian_ddim_reverse_sample": mtk.GaussianMultinomialDiffusion.gaussian_ddim_reverse_sample,
+        "diffusion.sample_ddim": mtk.GaussianMultinomialDiffusion.sample_ddim,
+        "ClavaDDPMTrainer": mtk.ClavaDDPMTrainer.__init__, "Classifier": mtk.Classifier.__init__,
+        "get_conditioning_function": mtk.get_conditioning_function, "MLPDiffusion": mtk.MLPDiffusion.__init__,
+        "mtk.inverse_transform_for": mtk.inverse_transform_for, "tabsyn.sample": tabsyn.sample,
+    }
+    seen = set()
+    tree = ast.parse(block)
+    for node in ast.walk(tree):
+        if not isinstance(node, ast.Call):
+            continue
+        name = ast.unparse(node.func)
+        fn = targets.get(name)
+        if fn is None:
+            continue
+        seen.add(name)
+        sig = inspect.signature(fn)
+        is_method = "self" in sig.parameters or "cls" in sig.parameters
+        args = ([None] if is_method else []) + [None] * len(node.args)
+        kwargs = {k.arg: None for k in node.keywords if k.arg is not None}
+        try:
+            sig.bind(*args, **kwargs)
+        except TypeError as e:
+            raise AssertionError(f"INTEGRATION.md shows `{ast.unparse(node)}`, which does not bind to {name}{sig}: {e}")
+    # positional meaning, where an order mistake would still bind: the driver's constructor and its keyed calls
+    call = next(n for n in ast.walk(tree) if isinstance(n, ast.Call) and ast.unparse(n.func) == "AttackFeatureDriver")
+    assert [ast.unparse(a) for a in call.args] == list(inspect.signature(mtk.AttackFeatureDriver.__init__).parameters)[1:4]
+    for meth in ("drv.add_model", "drv.features", "drv.challenge_predictions"):
+        call = next(n for n in ast.walk(tree) if isinstance(n, ast.Call) and ast.unparse(n.func) == meth)
+        assert isinstance(call.args[0], ast.Constant), f"{meth}: the first argument is the model key"
+    missing = {"AttackFeatureDriver", "drv.add_model", "drv.features", "drv.matrix", "mixed_loss", "ClavaDDPMTrainer"} - seen
+    assert not missing, missing
+    assert hasattr(distributed, "score_records_sharded") and hasattr(distributed, "sample_all_sharded")  # section 4 names them
