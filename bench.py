@@ -122,7 +122,7 @@ def timeit(fn, iters=5, warm=2):
     return float(np.median([s.elapsed_time(e) for s, e in ev])) * 1e-3
 
 
-def bench_sampling(mtk, dev, hidden, rows, dist, world, comm=False):
+def bench_sampling(mtk, dev, hidden, rows, dist, world, comm=False, warm_rows=None):
     """Sampled rows/s at T = 1000, shape M, in-kernel Philox noise (math "fast"), bf16 denoiser: every rank runs its own
     chain over `rows` rows (no collective inside the loop); value = world x rows / max-over-ranks time."""
     K, Nn, T = np.array([10] * 10), 20, 1000
@@ -132,7 +132,9 @@ def bench_sampling(mtk, dev, hidden, rows, dist, world, comm=False):
     net.precision = "bf16"
     d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
     d.precision, d.rng, d.results_on_device = "bf16", "philox", True
-    d.sample(rows, torch.ones(1), seed=1)  # warm-up: packs the weights, sizes the workspaces
+    d.sample(warm_rows or rows, torch.ones(1), seed=1)  # warm-up: packs the weights, sizes the workspaces
+    if warm_rows and warm_rows < rows:  # a small warm-up chain, then the workspaces and the first-touch of the timed batch's buffers
+        d.engine().reserve(rows)
     torch.cuda.synchronize()
     if comm:
         dist.barrier()
@@ -213,6 +215,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--sample-rows", type=int, default=262144)
+    ap.add_argument("--sample-rows-large", type=int, default=1 << 20, help="second sampling figure: one chain of BASELINE configs[3]'s 1M rows (0: skip)")
     ap.add_argument("--rehearse-rccl", action="store_true",
                     help="one GPU: initialise an RCCL (nccl) process group of ONE rank and run the N > 1 code path on it - the asynchronous, "
                          "double-buffered gather of the score blocks, the barriers, the MAX all-reduce of the time (what a one-GPU box can "
@@ -395,6 +398,10 @@ def main():
         extras["sampling_4x512"] = bench_sampling(mtk, dev, 512, a.sample_rows, dist, world, comm)
         extras["sampling_4x1024"] = bench_sampling(mtk, dev, 1024, a.sample_rows, dist, world, comm)
         out["sampled_rows_per_s"] = extras["sampling_4x1024"]["sampled_rows_per_s"]  # BASELINE configs[3]: 4x1024, shape M, T = 1000
+        if a.sample_rows_large > a.sample_rows:  # configs[3] at its own size: ONE chain of 1M rows (beyond what the Infinity Cache holds)
+            extras["sampling_4x1024_1M"] = bench_sampling(mtk, dev, 1024, a.sample_rows_large, dist, world, comm, warm_rows=8192)
+            extras["sampling_4x512_1M"] = bench_sampling(mtk, dev, 512, a.sample_rows_large, dist, world, comm, warm_rows=8192)
+            out["sampled_rows_per_s_1M_rows"] = extras["sampling_4x1024_1M"]["sampled_rows_per_s"]
         out["sampled_rows_per_s_4x512"] = extras["sampling_4x512"]["sampled_rows_per_s"]
     if not a.no_extras and world == 1 and not strong:
         extras["mixed_loss_shapeM"] = bench_mixed_loss(mtk, dev, 1 << 20)

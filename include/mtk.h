@@ -139,6 +139,18 @@ int mtk_mlp_set_weights(mtk_ctx* ctx, int n_hidden, const int32_t* dims_host, co
 int mtk_mlp_forward(mtk_ctx* ctx, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,
                     int t_scalar, float* out, int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream);
 
+/* Replaces the denoiser call of the reverse loop, GMD:1406: `self._denoise_fn(torch.cat([z_norm, log_z], dim=1).float(), t, ...)`.
+ * The reference materialises that input every step; here the denoiser reads the chain's state itself - z [Nn][state_ld] fp64 and
+ * z_idx [C][state_ld] int32 (column-major, as mtk_sample_init / mtk_p_sample_step keep them) - and forms float(z) and the
+ * log-one-hot rows on the fly, so the step kernels can be called with x_in_next = NULL and write no input matrix at all
+ * (480 of their 1,360 bytes per row at 20 numeric + 10 x 10 categorical columns).  One timestep t for all B rows; out as in
+ * mtk_mlp_forward.  Same arithmetic and rounding as mtk_mlp_forward on the materialised input: same output bits.
+ * mtk_mlp_state_input_ok says (1 / 0) whether the context's weights and `precision` have this path (today: MTK_PREC_BF16 on the
+ * layer-by-layer kernels, D <= 128, Nn <= 32, C <= 16); without it mtk_mlp_forward_state returns MTK_ERR_UNSUPPORTED. */
+int mtk_mlp_state_input_ok(mtk_ctx* ctx, int precision);
+int mtk_mlp_forward_state(mtk_ctx* ctx, int64_t B, const double* z, const int32_t* z_idx, int64_t state_ld, int t_scalar, float* out,
+                          int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream);
+
 /* No counterpart in the reference: mtk_mlp_forward(MTK_PREC_FP32) for callers that cannot allocate device memory -
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and results as
  * mtk_mlp_forward with MTK_PREC_FP32, but the activation ping-pong lives in a file-scope device array of the library
@@ -227,7 +239,8 @@ int mtk_ddim_reverse_step(mtk_ctx* ctx, int64_t B, int t, const float* model_out
 
 /* Replaces the initial draw of sample() (GMD:1392-1399): z0 [B, Nn] row-major fp32 (or NULL → Philox)
  * into the fp64 state z [Nn][B]; categories by Gumbel-argmax of uniform logits from u0 [B, S]
- * (or NULL → Philox) into z_idx [C][B]; and the first denoiser input. */
+ * (or NULL → Philox) into z_idx [C][B]; and the first denoiser input (x_in may be NULL when the denoiser reads the state:
+ * mtk_mlp_forward_state). */
 int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const float* u0, double* z, int32_t* z_idx,
                     float* x_in, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream);
 
@@ -318,6 +331,11 @@ int mtk_train_forward(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, c
                       float* loss_multi, float* loss_gauss, uint64_t seed, uint64_t row0, mtk_stream stream);
 int mtk_train_backward(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, double w_multi,
                        double w_gauss, uint64_t seed, uint64_t row0, mtk_stream stream);
+/* The same backward with the two weights read on the device: w_dev = {w_multi, w_gauss} (2 floats).  What an autograd seam has
+ * in hand are the incoming gradients of the two scalars as device tensors (TRAINER:90: loss.backward() hands 1 to each); reading
+ * them on the host would synchronise the stream once per iteration. */
+int mtk_train_backward_dev(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                           const float* w_dev, uint64_t seed, uint64_t row0, mtk_stream stream);
 /* TRAINER:92 + :133: torch.optim.AdamW.step() (decoupled decay, bias correction, step is 1-based) on images
  * 0/2/3 from image 1, then EMA image 4 <- ema_rate * image 4 + (1 - ema_rate) * image 0, then the
  * time-embedding table is rebuilt from the new weights.  The caller owns the learning-rate anneal

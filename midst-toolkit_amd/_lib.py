@@ -40,6 +40,8 @@ _SIGS = {
     "mtk_mlp_set_weights": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p]),
     "mtk_mlp_set_label_embedding": (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),
     "mtk_mlp_forward": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i32, _p, _i64, _i64, _i32, _p]),
+    "mtk_mlp_state_input_ok": (C.c_int, [_p, _i32]),
+    "mtk_mlp_forward_state": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _p, _i64, _i64, _i32, _p]),
     "mtk_mlp_forward_noalloc": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i32, _p, _i64, _i64, _p]),
     "mtk_q_sample": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _u64, _u64, _p]),
     "mtk_loss_rows": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),
@@ -64,6 +66,7 @@ _SIGS = {
     "mtk_train_set_deterministic": (C.c_int, [_p, _i32]),
     "mtk_train_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),
     "mtk_train_backward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, C.c_double, _u64, _u64, _p]),
+    "mtk_train_backward_dev": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _u64, _u64, _p]),
     "mtk_train_apply": (C.c_int, [_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _p]),
     "mtk_clf_create": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     "mtk_clf_destroy": (None, [_p]),

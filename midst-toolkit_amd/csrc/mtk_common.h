@@ -139,6 +139,9 @@ struct mtk_ctx {
     // workspace of the unfused Tartan-Federer path (x_t and eps_hat, row-major [rows][Nn])
     float* tf_ws[2] = {nullptr, nullptr};
     size_t tf_ws_elems = 0;
+    int64_t* tf_tvec = nullptr;  // per-row timesteps of the unfused Tartan-Federer path
+    size_t tf_tvec_elems = 0;
+    bool trusted_t = false;      // set around internal denoiser calls whose per-row timesteps the host has range-checked: skip the NaN pass
     float* tf_pack = nullptr;  // compact [B][round_up(Nn,4)] copy of the records for the fused Tartan-Federer kernel
     size_t tf_pack_elems = 0;
     TrainState train;

@@ -492,13 +492,13 @@ __global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
     const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
-        float* xo = a.x_in + row * a.xi_rs;
+        float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
         PhiloxN pn(seed_, row0_ + row, MTK_STREAM_Z0);
         PhiloxU pu(seed_, row0_ + row, MTK_STREAM_U0);
         for (int j = 0; j < Nn; ++j) {
             const float v = a.z0 ? a.z0[row * Nn + j] : pn.normal(j);
             a.z[(int64_t)j * a.B + row] = (double)v;
-            xo[j * a.xi_cs] = v;
+            if (xo) xo[j * a.xi_cs] = v;
         }
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
@@ -514,7 +514,8 @@ __global__ __launch_bounds__(kBlock) void k_sample_init(InitArgs a) {
                 arg = arg > Kk - 1 ? Kk - 1 : arg;
             }
             a.z_idx[(int64_t)k * a.B + row] = arg;
-            for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+            if (xo)
+                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
         }
     }
 }
@@ -716,7 +717,12 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
             xr = a.x0 + row * a.x0_ld;
         }
         if (row >= a.B) continue;
-        const int t = mtk_tclamp(a.t[row], a.d.T);
+        const int64_t tv = a.t[row];
+        const int t = mtk_tclamp(tv, a.d.T);
+        // a timestep outside [0, T): the record's outputs are NaN (mtk_tclamp keeps the addressing in bounds); folded into
+        // the stores here, so this path needs no k_poison_bad_t pass behind it (a launch and its gap per call)
+        const bool bad_t = tv < 0 || tv >= a.d.T;
+        const float qnan = __builtin_nanf("");
         float* xo = a.x_in + row * a.xi_rs;
         // first group of inputs in flight before anything is consumed
         float xv[kGroup], ev[kGroup];
@@ -741,7 +747,8 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
                 const int j = j0 + i;
                 if (j < Nn) {
                     const float e = a.eps ? ev[i] : pn.normal(j);
-                    xo[j * a.xi_cs] = sr.sqrt_acp * xv[i] + sr.sqrt_1m_acp * e;
+                    const float xt = sr.sqrt_acp * xv[i] + sr.sqrt_1m_acp * e;
+                    xo[j * a.xi_cs] = bad_t ? qnan : xt;
                 }
             }
 #pragma unroll
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
                     if (v > best || i == 0) { best = v; arg = i; }
                 }
                 a.xt_idx[(int64_t)k * a.B + row] = arg;
-                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = bad_t ? qnan : ((i == arg) ? 0.0f : MTK_LOG_TINY);
             }
             continue;
         }
@@ -790,7 +797,8 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
                     }
                     a.xt_idx[(int64_t)k * a.B + row] = arg;
                     float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
-                    for (int c = 0; c < Kk; ++c) xc[c * a.xi_cs] = (c == arg) ? 0.0f : MTK_LOG_TINY;
+                    const float hot_v = bad_t ? qnan : 0.0f, cold_v = bad_t ? qnan : MTK_LOG_TINY;
+                    for (int c = 0; c < Kk; ++c) xc[c * a.xi_cs] = (c == arg) ? hot_v : cold_v;
                 }
             }
         }
@@ -815,7 +823,9 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
             xr = a.x0 ? a.x0 + row * a.x0_ld : nullptr;
         }
         if (row >= a.B) continue;
-        const int t = mtk_tclamp(a.t[row], a.d.T);
+        const int64_t tv = a.t[row];
+        const int t = mtk_tclamp(tv, a.d.T);
+        const bool bad_t = tv < 0 || tv >= a.d.T;  // the multinomial loss of such a record is NaN (the MSE term does not depend on t)
         const float* mo = a.mo + row * a.mo_rs;
         const bool multi = a.loss_multi && C > 0;
         // Categorical blocks are requested TWO blocks ahead of their use (three rotating register images): a lane's chain
@@ -958,7 +968,7 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
             }
         }
         const float lt = (t == 0) ? -nll : kl;
-        a.loss_multi[row] = (lt * (float)T + prior) / (float)C;
+        a.loss_multi[row] = bad_t ? __builtin_nanf("") : (lt * (float)T + prior) / (float)C;
     }
 }
 
@@ -1140,6 +1150,9 @@ struct LossGradArgs {
     // kl_tab = the [T][4] coefficient table of k_gauss_kl_rows (null: MSE), kscale = w_gauss / (Nn ln 2)
     const double* kl_tab;
     float kscale;
+    // optional device pair {w_multi, w_gauss} that multiplies the two scales (mtk_train_backward_dev: the weights of the two loss
+    // sums are an autograd engine's incoming gradients, device scalars the host never reads); null: the scales stand as they are
+    const float* w_dev;
 };
 // derivative of DU:48-59's tanh approximation of the standard normal CDF
 __device__ __forceinline__ double approx_normal_cdf_grad(double v) {
@@ -1170,6 +1183,8 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
     const SchedRow srT = s.rows[T - 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float wdm = a.w_dev ? a.w_dev[0] : 1.0f, wdg = a.w_dev ? a.w_dev[1] : 1.0f;
+    const float gscale = a.gscale * wdg, kscale = a.kscale * wdg, mscale = a.mscale * wdm;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < a.B; base += (int64_t)gridDim.x * 64) {
         const int64_t row = base + lane;
         float accg = 0.0f, accm = 0.0f;
@@ -1187,7 +1202,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                     const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
                     const float df = mo[j * a.ld] - e;
                     accg += df * df;
-                    go[j * a.ld] = a.gscale * df;
+                    go[j * a.ld] = gscale * df;
                 }
             } else {
                 // _vb_terms_bpd (GMD:431-484) and its derivative with respect to the predicted noise: the model mean is
@@ -1220,7 +1235,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                         grad = pr > 1e-12 ? -(dpr / pr) * (double)slope : 0.0;  // clamp(min = 1e-12) passes no gradient below it
                     }
                     accg += (float)term;
-                    go[j * a.ld] = a.kscale * (float)grad;
+                    go[j * a.ld] = kscale * (float)grad;
                 }
             }
             for (int k = w; k < C; k += kLgWaves) {
@@ -1285,7 +1300,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 }
                 for (int i = 0; i < Kk; ++i) {
                     const float sm = ex<FAST>((mc[i * a.ld] - mx) - lsum);
-                    gc[i * a.ld] = a.mscale * (gc[i * a.ld] - sm * G);
+                    gc[i * a.ld] = mscale * (gc[i * a.ld] - sm * G);
                 }
             }
         }
@@ -1437,11 +1452,11 @@ int mtk_ensure_kl_tab(mtk_ctx* ctx) {
 // internal (mtk_train.hip): per-record losses and d(mean loss)/d(out); out / dout column-major [D][ld]
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
-                         float* dout, double w_multi, double w_gauss, uint64_t seed, uint64_t row0, hipStream_t stream) {
-    // d(w_gauss * sum_rows loss_gauss + w_multi * sum_rows loss_multi) / d out
+                         float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream) {
+    // d(w_gauss * sum_rows loss_gauss + w_multi * sum_rows loss_multi) / d out  (w_dev: both weights times the device pair)
     LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
                    ctx->Nn > 0 ? (float)(2.0 * w_gauss / ctx->Nn) : 0.0f,
-                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0, nullptr, 0.0f};
+                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0, nullptr, 0.0f, w_dev};
     if (ctx->train_gauss_kl && ctx->Nn > 0) {
         const int rc = mtk_ensure_kl_tab(ctx);
         if (rc) return rc;
@@ -1474,11 +1489,12 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
         hipLaunchKernelGGL((k_q_sample_fast<false, true>), dim3(grid_for(B, 16384)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
-        return mtk_poison_bad_t(t, B, ctx->T, x_in, xi_rs, xi_cs, ctx->D, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
+        return MTK_OK;  // the fast kernels poison records with an out-of-range timestep themselves
     }
     auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true, false> : k_q_sample_fast<false, false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
+    if (ctx->fast_math) return MTK_OK;
     return mtk_poison_bad_t(t, B, ctx->T, x_in, xi_rs, xi_cs, ctx->D, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
 }
 
@@ -1501,13 +1517,14 @@ extern "C" int mtk_loss_rows(mtk_ctx* ctx, int64_t B, const float* model_out, in
         hipLaunchKernelGGL(ks, dim3(grid_for(B)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);
         MTK_HIP(hipGetLastError());
-        return mtk_poison_bad_t(t, B, ctx->T, loss_multi, 1, 0, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);  // the MSE term does not depend on t
+        return MTK_OK;  // poisoned in the kernel
     }
     auto kf = small ? (lds ? k_loss_rows_fast_small<true, false> : k_loss_rows_fast_small<false, false>)
                     : (lds ? k_loss_rows_fast<true, false> : k_loss_rows_fast<false, false>);
     auto k = ctx->fast_math ? kf : (lds ? k_loss_rows<true> : k_loss_rows<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
+    if (ctx->fast_math) return MTK_OK;  // poisoned in the kernel
     return mtk_poison_bad_t(t, B, ctx->T, ctx->C > 0 ? loss_multi : nullptr, 1, 0, 1, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);  // the MSE term does not depend on t
 }
 
@@ -1620,7 +1637,7 @@ extern "C" int mtk_sample_init(mtk_ctx* ctx, int64_t B, const float* z0, const f
                                float* x_in, int64_t xi_rs, int64_t xi_cs, uint64_t seed, uint64_t row0, mtk_stream stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null context");
     if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
-    if (B < 0 || !x_in || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null pointer or negative B");
+    if (B < 0 || (ctx->Nn > 0 && !z) || (ctx->C > 0 && !z_idx)) MTK_FAIL(MTK_ERR_ARG, "mtk_sample_init: null pointer or negative B");  // x_in may be NULL (mtk_mlp_forward_state reads the state)
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
     InitArgs a{ctx->dev(), B, z0, u0, z, z_idx, x_in, xi_rs, xi_cs, seed, row0, ctx->seed_src};

@@ -917,7 +917,7 @@ int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64
     a.tvec = t; a.t_scalar = t_scalar; a.T = c->T;
     a.out = out; a.o_rs = o_rs; a.o_cs = o_cs;
     const int rc = run(c, a, s);
-    return rc ? rc : mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
+    return rc ? rc : mtk_poison_bad_t(c->trusted_t ? nullptr : t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
 }
 
 // compact [records][round_up(Nn, 4)] copy of the records (used when the caller's rows are not 16-byte aligned / compact)

@@ -417,6 +417,210 @@ __global__ __launch_bounds__(512, 1) void k_gemm_bf16(GemmB g) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// First block of a one-timestep launch whose input is the reverse chain's STATE (mtk_mlp_forward_state): the denoiser
+// input of GMD:1406 is cat[float(z), log-one-hot(z_idx)], which the step kernel used to write out as 480 B/row of fp32
+// (and k_x_to_bf16 then re-read and re-wrote as bf16).  Here a workgroup builds the bf16 operand tile of its 256 records
+// in LDS straight from z [Nn][ld] (fp64, what the step kernel keeps anyway) and z_idx [C][ld]: 200 B/row read, nothing
+// written, no conversion launch.  Same rounding as the old route (double -> float -> bf16, both round-to-nearest-even;
+// log(1e-30) rounded to bf16 once), same folded weights W1 Wp and bias row embf[t], same MFMA order over k: same output
+// bits.  K = kp0 <= 128 (one or two 64-wide k-blocks), so the whole weight tile of a column tile (<= 64 KB) stays in
+// LDS while the workgroup walks its record tiles; the launch is bound by its output stores (134 MB per 65,536 rows).
+// LDS image of a k-block: as in k_gemm_bf16 (row r, 16-byte piece p at r * 128 + ((p ^ ((r >> 1) & 7)) * 16)).
+struct FirstArgs {
+    int64_t M, MT;           // valid rows of this pass, row tiles (of 256)
+    int nb_n, nkb;           // column tiles (of 256), k-blocks (1 or 2)
+    int Nn, C, D;
+    const int32_t* off;      // [C + 1] one-hot column offsets (device)
+    const double* z; const int32_t* z_idx; int64_t ld;   // state of this pass's first row; column stride ld
+    const uint16_t* W; int64_t w_ld;                      // bf16 [Npad][w_ld], w_ld = nkb * 64
+    const float* bias;                                    // [Npad]: row t of the folded bias table
+    uint16_t* Y; int64_t y_rs;                            // bf16 [Mpad][y_rs]
+};
+
+constexpr int kStateMaxNn = 32, kStateMaxC = 16;  // what a thread prefetches into registers (mtk_mlp_forward_state's limits)
+
+__global__ __launch_bounds__(512, 1) void k_first_state(FirstArgs g) {
+    constexpr int MW = 4, WC = 4, BM = 256, BN = 256;
+    constexpr int kTile = BM * BK * 2;  // bytes of one k-block of the record or of the weight tile (32 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC, li = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, wq = blockIdx.x >> 3, wstride = gridDim.x >> 3;
+    const int64_t slots = ((g.MT - xcd + 7) / 8) * g.nb_n;
+    if (wq >= slots) return;
+    unsigned char* lds = reinterpret_cast<unsigned char*>(gb_smem);
+    unsigned char* ldsW = lds + 2 * kTile;
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    const __bf16 cold_b = (__bf16)MTK_LOG_TINY;
+    const uint16_t cold = *reinterpret_cast<const uint16_t*>(&cold_b);
+    // thread (r, half) owns the 16-byte pieces p = half, half + 2, ... of record r's operand row
+    const int r = tid & 255, half = __builtin_amdgcn_readfirstlane(tid >> 8);  // half is wave-uniform: column bases stay scalar
+    // The state of a tile is requested into registers BEFORE the previous tile's output stores are issued: vector memory
+    // operations retire in order, so a wait for loads issued behind 128 KB of stores would wait for the stores to drain
+    // (the launch is bound by them) - this way the stores drain under the next tile's operand build and MFMAs.
+    double zpf[2][8];
+    int ipf[kStateMaxC];
+    auto prefetch = [&](int64_t slot) {
+        const int64_t row = ((slot / g.nb_n) * 8 + xcd) * BM + r;
+        const bool live = row < g.M;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = (half + 2 * q) * 8 + i;
+                zpf[q][i] = (live && k < g.Nn) ? g.z[(int64_t)k * g.ld + row] : 0.0;
+            }
+#pragma unroll
+        for (int k = 0; k < kStateMaxC; ++k) ipf[k] = (live && k < g.C) ? g.z_idx[(int64_t)k * g.ld + row] : -1;
+    };
+    prefetch(wq);
+    // one-hot column offsets: a copy in LDS behind the two tiles (as scalar loads the compiler hoists all of them out of the
+    // tile loop and spills them)
+    int* offs = reinterpret_cast<int*>(lds + 4 * kTile);
+    if (tid <= g.C) offs[tid] = g.off[tid];
+    __syncthreads();
+    int n_have = -1;
+    f32x16 acc[MW][NT];
+    for (int64_t slot = wq; slot < slots; slot += wstride) {
+        const int64_t m0 = ((slot / g.nb_n) * 8 + xcd) * BM;
+        const int ntile = (int)(slot % g.nb_n), n0 = ntile * BN;
+        const bool new_w = ntile != n_have;
+        if (new_w) {  // weight tile of this column tile: 8-row, 1-KiB pieces by LDS-DMA, 4 per wave and k-block
+            n_have = ntile;
+            const int lr = lane >> 3;
+            for (int kb = 0; kb < g.nkb; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int chunk = wv * 4 + j;  // rows chunk * 8 .. + 8 of the tile
+                    const int lc = (lane & 7) ^ ((lr >> 1) | ((chunk & 1) << 2));
+                    const unsigned voff = (unsigned)(lr * g.w_ld * 2 + lc * 16);
+                    const unsigned char* gp = reinterpret_cast<const unsigned char*>(g.W + ((int64_t)n0 + chunk * 8) * g.w_ld + kb * BK);
+                    const unsigned m0v = (unsigned)(2 * kTile + kb * kTile + chunk * 1024);
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gp), "s"(m0v) : "memory");
+                }
+        }
+        // ---- the record tile from the prefetched state
+        {
+            int r_ = r;
+            asm volatile("" : "+v"(r_));  // addresses below are formed per tile, not hoisted out of the tile loop and kept alive
+            const bool live = m0 + r_ < g.M;
+            const int np = g.nkb * 8;  // 16-byte pieces of a row
+            unsigned char* rowp = lds + r_ * 128;
+            const int key_ = (r_ >> 1) & 7;
+            auto put = [&](int p, const uint16_t (&v)[8]) {
+                const uint4 w4 = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16));
+                *reinterpret_cast<uint4*>(rowp + (p >> 3) * kTile + (((p & 7) ^ key_) * 16)) = w4;
+            };
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {  // the (partly) numeric pieces: float(z) rounded to bf16
+                const int p = half + 2 * q, k0 = p * 8;
+                if (p < np) {
+                    uint16_t v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        // two roundings, as on the materialised route (fp64 state -> .float() -> bf16 operand): kept apart by an opaque
+                        // copy, or the compiler folds them into one fp64 -> bf16 conversion (a different result on ties: 1 value in 1e5)
+                        float zf = (float)zpf[q][i];
+                        asm volatile("" : "+v"(zf));
+                        const __bf16 b = (__bf16)zf;
+                        const uint16_t e = (k0 + i < g.Nn) ? *reinterpret_cast<const uint16_t*>(&b) : ((k0 + i < g.D) ? cold : (uint16_t)0);
+                        v[i] = live ? e : (uint16_t)0;
+                    }
+                    put(p, v);
+                }
+            }
+#pragma unroll 1
+            for (int p = half + 4; p < np; p += 2) {  // all-categorical (or padding) pieces
+                uint16_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (live && p * 8 + i < g.D) ? cold : (uint16_t)0;
+                put(p, v);
+            }
+            asm volatile("" ::: "memory");  // the fills above before the two-byte stores below (different access types)
+            // the hot column of every categorical block: log(1) = 0.  The owner of the piece writes it, after its own fill
+            // (LDS operations of one wave execute in order).
+#pragma unroll
+            for (int k = 0; k < kStateMaxC; ++k)
+                if (k < g.C && ipf[k] >= 0) {
+                    const int col = g.Nn + offs[k] + ipf[k];
+                    const int p = col >> 3;
+                    if ((p & 1) == half && p < np) *reinterpret_cast<volatile uint16_t*>(rowp + (p >> 3) * kTile + (((p & 7) ^ key_) * 16) + (col & 7) * 2) = 0;
+                }
+        }
+        // accumulators start from the bias (scalar loads, as in k_gemm_bf16)
+        {
+            const float* bp = g.bias + n0 + (wv % WC) * WN;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x8 b0, b1, b2, b3;
+                asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&s"(b0), "=&s"(b1), "=&s"(b2), "=&s"(b3)
+                             : "s"(bp + nt * 32)
+                             : "memory");
+                const f32x8 bq[4] = {b0, b1, b2, b3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float bv = hh ? bq[q][4 + j] : bq[q][j];
+#pragma unroll
+                        for (int a = 0; a < MW; ++a) acc[a][nt][4 * q + j] = bv;
+                    }
+            }
+        }
+        if (new_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's weight pieces have landed (first tile: nothing else is in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < g.nkb; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fa[MW], fb[NT];
+                const int kp = ks * 2 + hh;
+#pragma unroll
+                for (int q = 0; q < MW; ++q) {
+                    const int ra = (wr * MW + q) * 32 + li;
+                    fa[q] = *reinterpret_cast<const bf16x8*>(lds + kb * kTile + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    const int rb = wc * WN + q * 32 + li;
+                    fb[q] = *reinterpret_cast<const bf16x8*>(ldsW + kb * kTile + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's fragment reads are done: the next tile's build may overwrite the record image
+        if (slot + wstride < slots) prefetch(slot + wstride);  // before this tile's stores (see above)
+        // epilogue: ReLU, bf16, v_permlane32_swap pairs the two half-pieces of a record's 16 bytes (see k_gemm_bf16)
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            const int64_t row = m0 + (wr * MW + mt) * 32 + li;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                unsigned pk[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __bf16 e[4] = {(__bf16)fmaxf(acc[mt][nt][4 * q], 0.0f), (__bf16)fmaxf(acc[mt][nt][4 * q + 1], 0.0f),
+                                         (__bf16)fmaxf(acc[mt][nt][4 * q + 2], 0.0f), (__bf16)fmaxf(acc[mt][nt][4 * q + 3], 0.0f)};
+                    pk[q][0] = reinterpret_cast<const unsigned*>(e)[0];
+                    pk[q][1] = reinterpret_cast<const unsigned*>(e)[1];
+                }
+                uint16_t* yb = g.Y + row * g.y_rs + n0 + wc * WN + nt * 32;
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][0], pk[2 * p2][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][1], pk[2 * p2][1], false, false);
+                    *reinterpret_cast<uint4*>(yb + 8 * (2 * p2 + (hh ? 0 : 1))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            }
+        }
+    }
+}
+
 __global__ void k_to_bf16_pad(uint16_t* dst, int rows_pad, int cols_pad, const float* src, int src_ld, int rows, int cols) {
     const int64_t n = (int64_t)rows_pad * cols_pad;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -663,9 +867,39 @@ int ensure_ws16(mtk_ctx* c, int64_t B, bool split, hipStream_t s) {
     return MTK_OK;
 }
 
+// can the first block take its input from the chain's state (k_first_state)?  Plain bf16 with the folded first block, an
+// operand row of at most two k-blocks, and no more numeric / categorical columns than a thread prefetches into registers
+bool state_input_ok(const mtk_ctx* c) {
+    return !c->wb16.empty() && c->wb16_fold && c->embf_l && !c->blocks.empty() && round_up(c->proj.in_pad, BK) <= 2 * BK && c->Nn <= kStateMaxNn &&
+           c->C <= kStateMaxC && c->wb16.size() == c->blocks.size() + 2;
+}
+
+int launch_first_state(mtk_ctx* c, FirstArgs& g, int64_t Mpad, int Npad, hipStream_t s) {
+    constexpr size_t lds = 4 * 256 * BK * 2 + 128;  // record tile + weight tile, two k-blocks each (128 KB) + the one-hot offsets
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_first_state), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (Mpad % 256 || Npad % 256) MTK_FAIL(MTK_ERR_STATE, "state-input block: %lld x %d is not a multiple of the 256 x 256 tile", (long long)Mpad, Npad);
+    g.MT = Mpad / 256;
+    g.nb_n = Npad / 256;
+    int64_t per_xcd = n_cus_layered(c->device) / 8;
+    if (per_xcd < 1) per_xcd = 1;
+    const int64_t most = ((g.MT + 7) / 8) * g.nb_n;
+    if (most < per_xcd) per_xcd = most;
+    hipLaunchKernelGGL(k_first_state, dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, g);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+// zst / zi / st_ld: the reverse chain's state (fp64 [Nn][st_ld], int32 [C][st_ld]) as the denoiser's input instead of x
 template <bool SPLIT>
 int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar, float* out,
-                    int64_t o_rs, int64_t o_cs, hipStream_t s) {
+                    int64_t o_rs, int64_t o_cs, hipStream_t s, const double* zst = nullptr, const int32_t* zi = nullptr, int64_t st_ld = 0) {
+    const bool from_state = zst || zi;
+    if (from_state && (SPLIT || t || !state_input_ok(c) || t_scalar < 0 || t_scalar >= c->T))
+        MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward_state: this denoiser / precision takes its input as a matrix (mtk_mlp_forward)");
     const std::vector<void*>& wimg = SPLIT ? c->wb16x : c->wb16;
     if (wimg.size() != c->blocks.size() + 2) MTK_FAIL(MTK_ERR_STATE, "layered bf16 denoiser: weights are not packed");
     constexpr int F = SPLIT ? 2 : 1;  // bf16 numbers per activation / weight
@@ -680,8 +914,10 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         int rc;
         // input -> bf16 [Mpad][F kp0]
         const int kp0 = round_up(c->proj.in_pad, BK);
-        hipLaunchKernelGGL(k_x_to_bf16<SPLIT>, dim3((unsigned)(Mpad / 64), (unsigned)((kp0 + 127) / 128)), dim3(256), 0, s, ws[0], kp0, x + r0 * x_rs, x_rs, x_cs, M, c->D);
-        MTK_HIP(hipGetLastError());
+        if (!from_state) {
+            hipLaunchKernelGGL(k_x_to_bf16<SPLIT>, dim3((unsigned)(Mpad / 64), (unsigned)((kp0 + 127) / 128)), dim3(256), 0, s, ws[0], kp0, x + r0 * x_rs, x_rs, x_cs, M, c->D);
+            MTK_HIP(hipGetLastError());
+        }
         int cur = 0;
         // one timestep for the whole launch (plain bf16): proj is folded into the first block, whose bias is row t of embf_l
         const bool fold = !SPLIT && !t && c->wb16_fold && c->embf_l && t_scalar >= 0 && t_scalar < c->T;
@@ -700,6 +936,18 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         for (size_t i = 0; i < c->blocks.size(); ++i) {
             const MlpLayer& l = c->blocks[i];
             const bool folded = fold && i == 0;
+            if (folded && from_state) {  // the folded first block with its operand built in LDS from the state
+                FirstArgs f{};
+                f.M = M; f.nkb = kp0 / BK; f.Nn = c->Nn; f.C = c->C; f.D = c->D; f.off = c->d_off;
+                f.z = zst ? zst + r0 : nullptr; f.z_idx = zi ? zi + r0 : nullptr; f.ld = st_ld;
+                f.W = reinterpret_cast<const uint16_t*>(c->wb16_fold); f.w_ld = kp0;
+                f.bias = c->embf_l + (size_t)t_scalar * c->embf_ld;
+                ld = round_up(l.out_pad, BT);
+                f.Y = ws[cur ^ 1]; f.y_rs = ld;
+                if ((rc = launch_first_state(c, f, Mpad, ld, s))) return rc;
+                cur ^= 1;
+                continue;
+            }
             GemmB h{};
             h.M = M; h.N = l.out; h.Kpad = folded ? kp0 : round_up(l.in_pad, BK);
             h.X = ws[cur]; h.x_ld = (int64_t)F * ld; h.x_lo = ld;
@@ -719,7 +967,7 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         else rc = launch<true, 2, 4, false, SPLIT>(h, c->device, Mpad, round_up(c->head.out_pad, BT), s);
         if (rc) return rc;
     }
-    return mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
+    return mtk_poison_bad_t(c->trusted_t ? nullptr : t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
 }
 
 }  // namespace
@@ -727,6 +975,13 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
 int mtk_reserve_layered(mtk_ctx* c, int64_t rows, hipStream_t s) {  // mtk_ctx_reserve: the split image is the larger one
     if (c->wb16x.empty() && c->wb16.empty()) return MTK_OK;
     return ensure_ws16(c, rows, !c->wb16x.empty(), s);
+}
+
+bool mtk_layered_state_input_ok(const mtk_ctx* c) { return state_input_ok(c); }
+
+int mtk_layered_bf16_forward_state(mtk_ctx* c, int64_t B, const double* z, const int32_t* z_idx, int64_t ld, int t_scalar, float* out, int64_t o_rs,
+                                   int64_t o_cs, hipStream_t s) {
+    return forward_layered<false>(c, B, nullptr, 0, 0, nullptr, t_scalar, out, o_rs, o_cs, s, z, z_idx, ld);
 }
 
 int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,

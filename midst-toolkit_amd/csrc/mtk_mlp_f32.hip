@@ -15,6 +15,9 @@ void mtk_free_layered(mtk_ctx* c);                // mtk_mlp_bf16_layered.hip
 int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain);  // mtk_mlp_bf16_layered.hip
 int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                              float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16_layered.hip
+bool mtk_layered_state_input_ok(const mtk_ctx* c);
+int mtk_layered_bf16_forward_state(mtk_ctx* c, int64_t B, const double* z, const int32_t* z_idx, int64_t ld, int t_scalar, float* out, int64_t o_rs,
+                                   int64_t o_cs, hipStream_t s);
 int mtk_fused_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                       float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16.hip
 int mtk_layered_bf16x3_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
@@ -233,6 +236,9 @@ void mtk_free_mlp(mtk_ctx* c) {
         c->tf_ws[i] = nullptr;
     }
     c->tf_ws_elems = 0;
+    if (c->tf_tvec) (void)hipFree(c->tf_tvec);
+    c->tf_tvec = nullptr;
+    c->tf_tvec_elems = 0;
     mtk_free_fused(c);
     mtk_free_layered(c);
     mtk_free_train(c);
@@ -370,7 +376,7 @@ static int forward_f32_ws(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, i
         h.act = ACT_NONE; h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
         if ((rc = launch_gemm<false, true>(h, Mpad, c->head.out_pad, s))) return rc;
     }
-    return mtk_poison_bad_t(t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
+    return mtk_poison_bad_t(c->trusted_t ? nullptr : t, B, c->T, out, o_rs, o_cs, c->D, nullptr, 0, 0, 0, nullptr, s);
 }
 
 static int max_pad_of(const mtk_ctx* c) {
@@ -410,10 +416,16 @@ int mtk_reserve_layered(mtk_ctx* c, int64_t rows, hipStream_t s);  // mtk_mlp_bf
 int mtk_reserve_tf(mtk_ctx* c, int64_t rows, hipStream_t s);       // mtk_tf.hip
 int mtk_reserve_train(mtk_ctx* c, int64_t rows, hipStream_t s);    // mtk_train.hip
 
+int64_t mtk_tf_chunk_rows(int64_t BP);  // mtk_tf.hip
+
 static int reserve_all(mtk_ctx* c, int64_t rows, hipStream_t s) {
     int rc;
-    if ((rc = ensure_ws_f32(c, rows, s))) return rc;
-    if ((rc = mtk_reserve_layered(c, rows, s))) return rc;
+    // a numeric-only context may score `rows` = B * P rows per timestep (mtk_tf_score): its unfused path hands the denoiser
+    // chunks that span timesteps, up to mtk_tf_chunk_rows(rows) rows
+    const int64_t tf_rows = (c->S == 0 && c->Nn > 0) ? mtk_tf_chunk_rows(rows) : 0;
+    const int64_t dn_rows = rows > tf_rows ? rows : tf_rows;
+    if ((rc = ensure_ws_f32(c, dn_rows, s))) return rc;
+    if ((rc = mtk_reserve_layered(c, dn_rows, s))) return rc;
     if ((rc = mtk_reserve_tf(c, rows, s))) return rc;
     return mtk_reserve_train(c, rows, s);
 }
@@ -472,6 +484,26 @@ extern "C" int mtk_mlp_forward_noalloc(mtk_ctx* c, int64_t B, const float* x, in
     float* base = g_noalloc_ptr[c->device];
     return forward_f32_ws(c, B, x, x_rs, x_cs, t, t_scalar, out, o_rs, o_cs, base, base + kNoallocRows * kNoallocWidth, kNoallocRows,
                           (hipStream_t)stream);
+}
+
+// The denoiser on the reverse chain's STATE instead of on a materialised input matrix (GMD:1406 forms
+// cat[z_norm, log_z].float() every step): 1 when this context's weights and `precision` have such a path.
+extern "C" int mtk_mlp_state_input_ok(mtk_ctx* c, int precision) {
+    if (!c || !c->have_weights || c->train.attached) return 0;
+    return (precision == MTK_PREC_BF16 && !c->fused_ok && mtk_layered_state_input_ok(c)) ? 1 : 0;
+}
+
+extern "C" int mtk_mlp_forward_state(mtk_ctx* c, int64_t B, const double* z, const int32_t* z_idx, int64_t state_ld, int t_scalar, float* out,
+                                     int64_t o_rs, int64_t o_cs, int precision, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_state: null context");
+    if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_mlp_forward_state: call mtk_mlp_set_weights first");
+    if (B == 0) return MTK_OK;
+    if (B < 0 || !out || (c->Nn > 0 && !z) || (c->C > 0 && !z_idx) || state_ld < B) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_state: null pointer, negative B or state_ld < B");
+    if (t_scalar < 0 || t_scalar >= c->T) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_forward_state: t = %d outside [0, %d)", t_scalar, c->T);
+    if (!mtk_mlp_state_input_ok(c, precision))
+        MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_mlp_forward_state: no state-input path for this denoiser shape / precision (use mtk_mlp_forward)");
+    MTK_HIP(hipSetDevice(c->device));
+    return mtk_layered_bf16_forward_state(c, B, z, z_idx, state_ld, t_scalar, out, o_rs, o_cs, (hipStream_t)stream);
 }
 
 extern "C" int mtk_mlp_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t,

@@ -19,7 +19,7 @@
 
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
-                         float* dout, double w_multi, double w_gauss, uint64_t seed, uint64_t row0, hipStream_t stream);  // mtk_diffusion.hip
+                         float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream);  // mtk_diffusion.hip
 
 namespace {
 
@@ -592,7 +592,7 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
 // activations the last FORWARD on this context left behind (x0 / t / eps / seed / row0 must be that call's).
 static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u,
                         double w_multi, double w_gauss, float* loss_multi, float* loss_gauss, uint64_t seed, uint64_t row0,
-                        bool do_fwd, bool do_bwd, mtk_stream stream) {
+                        bool do_fwd, bool do_bwd, mtk_stream stream, const float* w_dev = nullptr) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null context");
     if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_step: call mtk_train_attach first");
     if (B <= 0 || !x0 || !t) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null pointer or B <= 0");
@@ -647,14 +647,14 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     }
     }
     if (!do_bwd) {  // losses only (the gradient scratch it also fills is rewritten by the backward phase)
-        return mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout, 0.0, 0.0, seed, row0, s);
+        return mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout, 0.0, 0.0, nullptr, seed, row0, s);
     }
     MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
     MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
     MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
     // ---- loss and d loss / d out (column-major, rows >= B and features >= D stay zero)
     if ((rc = mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout,
-                                   w_multi, w_gauss, seed, row0, s)))
+                                   w_multi, w_gauss, w_dev, seed, row0, s)))
         return rc;
 
     // ---- backward
@@ -865,6 +865,12 @@ extern "C" int mtk_train_forward(mtk_ctx* c, int64_t B, const float* x0, int64_t
 extern "C" int mtk_train_backward(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
                                   double w_multi, double w_gauss, uint64_t seed, uint64_t row0, mtk_stream stream) {
     return train_phases(c, B, x0, x0_ld, t, eps, nullptr, w_multi, w_gauss, nullptr, nullptr, seed, row0, false, true, stream);
+}
+
+extern "C" int mtk_train_backward_dev(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
+                                      const float* w_dev, uint64_t seed, uint64_t row0, mtk_stream stream) {
+    if (!w_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_train_backward_dev: null weight pair");
+    return train_phases(c, B, x0, x0_ld, t, eps, nullptr, 1.0, 1.0, nullptr, nullptr, seed, row0, false, true, stream, w_dev);
 }
 
 extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, double beta1, double beta2, double eps,

@@ -71,9 +71,11 @@ class _MixedLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_multi, g_gauss):
         x0, t, eps = ctx.inputs
-        w_multi = float(g_multi) / ctx.B if g_multi is not None else 0.0
-        w_gauss = float(g_gauss) / ctx.B if g_gauss is not None else 0.0
-        ctx.eng.train_backward(ctx.token, x0, t, eps, w_multi, w_gauss, seed=ctx.seed)
+        # the incoming gradients stay on the device ([w_multi, w_gauss] = g / B, read by the loss-gradient kernel): no host sync
+        zero = torch.zeros((), dtype=torch.float32, device=x0.device)
+        w_dev = torch.stack([(g_multi if g_multi is not None else zero).to(x0.device, torch.float32).reshape(()),
+                             (g_gauss if g_gauss is not None else zero).to(x0.device, torch.float32).reshape(())]) / ctx.B
+        ctx.eng.train_backward_dev(ctx.token, x0, t, eps, w_dev.contiguous(), seed=ctx.seed)
         bufs = [(torch.empty_like(W.data), torch.empty_like(b.data)) for W, b in ctx.net._weights()]
         ctx.eng.train_export("grads", bufs)
         flat = [g for pair in bufs for g in pair]
@@ -139,6 +141,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         self.results_on_device = False  # True: sample / sample_all return device tensors (the reference moves them to the CPU, GMD:1423),
         #                                 so that e.g. transforms.QuantileInverse runs on them without a host round trip
         self.rng = "torch"  # "torch": draw like the reference does; "philox": draw inside the kernels
+        self.state_input = True  # reverse chain: let the denoiser read the chain's state (z, z_idx) where the library has that path
+        #                          (mtk_mlp_forward_state: no [B, D] input matrix is written or converted per step); False: always materialise it
         self.use_graph = False  # rng="philox" only: run the reverse chain of sample() as one captured HIP graph (_replay_chain_graph)
         self.math = None    # None: "fast" with rng="philox", "reference" otherwise; or force "reference"/"fast"
         self.precision = getattr(denoise_fn, "precision", "fp32")
@@ -435,11 +439,15 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             return (sample if getattr(self, "results_on_device", False) else sample.cpu()), outputs
         z = torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev)
         z_idx = torch.empty((max(C, 1), B), dtype=torch.int32, device=dev)
-        x_in = torch.empty((D, B), dtype=torch.float32, device=dev)
+        from_state = self._state_route(eng, ddim, y)
+        x_in = None if from_state else torch.empty((D, B), dtype=torch.float32, device=dev)
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
         eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed, row0)
         for i, t in enumerate(reversed(range(T))):
-            self._denoise_cm(eng, x_in, t, B, out, y)
+            if from_state:  # GMD:1406's cat[z_norm, log_z].float() is formed inside the denoiser's first block
+                eng.mlp_forward_state(z, z_idx, t, out, B, self.precision, out_strides=(1, B))
+            else:
+                self._denoise_cm(eng, x_in, t, B, out, y)
             n = u = grad = None
             if inj is not None:
                 n = inj["noise"][i] if Nn and not ddim else None
@@ -469,6 +477,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         sample = sample.float() if ddim else sample  # the reference's DDIM chain is fp32 end to end
         return (sample if getattr(self, "results_on_device", False) else sample.cpu()), outputs
 
+    def _state_route(self, eng: Engine, ddim: bool, y) -> bool:
+        """Does this chain's denoiser read the state directly (Engine.mlp_forward_state) instead of a materialised input?"""
+        return bool(getattr(self, "state_input", True)) and not ddim and y is None and not self._label_net() and eng.state_input_ok(self.precision)
+
     def _replay_chain_graph(self, eng: Engine, B: int, seed: int, row0: int) -> Tensor:
         """The whole reverse chain of ``B`` rows - mtk_sample_init, T x (denoiser, mtk_p_sample_step), mtk_sample_decode: 2 T + 2
         launches - as ONE HIP graph (GMD:1403-1417 is a Python loop of T iterations in the reference).  In-kernel Philox noise
@@ -479,7 +491,8 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         replays allocate nothing and make one launch call.  Same kernels and arguments as the eager loop: same samples."""
         dev = eng.device
         Nn, C, D, T = eng.Nn, eng.C, eng.D, self.num_timesteps
-        key = (B, str(dev), self.precision, self.math, getattr(self._denoise_fn, "_synced_key", None), id(eng))
+        from_state = self._state_route(eng, False, None)
+        key = (B, str(dev), self.precision, self.math, getattr(self._denoise_fn, "_synced_key", None), id(eng), from_state)
         cache = self.__dict__.setdefault("_graphs", {})
 
         def generation():
@@ -500,7 +513,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             ent = {"seed": torch.zeros(2, dtype=torch.int64, device=dev),
                    "z": torch.empty((max(Nn, 1), B), dtype=torch.float64, device=dev),
                    "z_idx": torch.empty((max(C, 1), B), dtype=torch.int32, device=dev),
-                   "x_in": torch.empty((D, B), dtype=torch.float32, device=dev),
+                   "x_in": None if from_state else torch.empty((D, B), dtype=torch.float32, device=dev),
                    "out": torch.empty((D, B), dtype=torch.float32, device=dev),
                    "sample": torch.empty((B, Nn + C), dtype=torch.float64, device=dev)}
             eng.reserve(B)
@@ -510,7 +523,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                 for i, t in enumerate(reversed(range(T))):
                     if i >= steps:
                         break
-                    self._denoise_cm(eng, ent["x_in"], t, B, ent["out"])
+                    if from_state:
+                        eng.mlp_forward_state(ent["z"], ent["z_idx"], t, ent["out"], B, self.precision, out_strides=(1, B))
+                    else:
+                        self._denoise_cm(eng, ent["x_in"], t, B, ent["out"])
                     eng.p_sample_step(B, t, i == 0, ent["out"], (1, B), ent["z"], ent["z_idx"], None, None, ent["x_in"], (1, B), 0, 0)
                 eng.sample_decode(B, ent["z"], ent["z_idx"], ent["sample"])
 

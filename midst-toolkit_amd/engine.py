@@ -136,6 +136,22 @@ class Engine:
                                              PRECISIONS[precision], self._stream()))
         return out
 
+    def state_input_ok(self, precision: str) -> bool:
+        """Can the denoiser read the reverse chain's state (z, z_idx) directly at this precision (mtk_mlp_state_input_ok)?"""
+        return bool(_lib.lib().mtk_mlp_state_input_ok(self._h, PRECISIONS[precision]))
+
+    def mlp_forward_state(self, z: torch.Tensor, z_idx: torch.Tensor, t: int, out: torch.Tensor, B: int, precision: str = "bf16",
+                          out_strides=None) -> torch.Tensor:
+        """The denoiser of one reverse step on the chain's state: z [max(Nn, 1), B] fp64 and z_idx [max(C, 1), B] int32 (column-major
+        state of mtk_sample_init / mtk_p_sample_step) instead of the materialised [B, D] input (mtk_mlp_forward_state)."""
+        assert z.dtype == torch.float64 and z_idx.dtype == torch.int32 and z.is_contiguous() and z_idx.is_contiguous()
+        assert z.shape[1] == B and z_idx.shape[1] == B
+        os_ = out_strides if out_strides is not None else (out.stride(0), out.stride(1))
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_mlp_forward_state(self._h, B, ptr(z), ptr(z_idx), B, int(t), ptr(out), os_[0], os_[1], PRECISIONS[precision],
+                                                   self._stream()))
+        return out
+
     def mlp_forward_noalloc(self, x: torch.Tensor, t, out: torch.Tensor, x_strides=None, out_strides=None, B: int | None = None) -> torch.Tensor:
         """mtk_mlp_forward_noalloc: the exact-fp32 denoiser through the library's static device scratch (no hipMalloc /
         hipFree / synchronisation inside the call; B <= 4096 rows, layers <= 1024 wide).  ``out`` is caller-allocated."""
@@ -309,6 +325,17 @@ class Engine:
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_train_backward(self._h, x0.shape[0], ptr(x0), x0.stride(0), ptr(t), ptr(eps), float(w_multi), float(w_gauss),
                                                 seed, row0, self._stream()))
+
+    def train_backward_dev(self, token, x0, t, eps, w_dev: torch.Tensor, seed=0, row0=0) -> None:
+        """train_backward with the weights of the two loss sums in a device tensor ``w_dev`` = [w_multi, w_gauss] (fp32): no host
+        read of an autograd gradient, so no stream synchronisation (mtk_train_backward_dev)."""
+        if token != getattr(self, "_fwd_token", None):
+            raise RuntimeError("backward through mixed_loss after another differentiable mixed_loss call on the same model: "
+                               "the context keeps the activations of one forward pass at a time")
+        assert w_dev.is_cuda and w_dev.dtype == torch.float32 and w_dev.numel() == 2 and w_dev.is_contiguous()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_backward_dev(self._h, x0.shape[0], ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(w_dev), seed, row0,
+                                                    self._stream()))
 
     def train_apply(self, lr, weight_decay, step, betas=(0.9, 0.999), eps=1e-8, ema_rate=0.999) -> None:
         with torch.cuda.device(self.device):

@@ -24,7 +24,7 @@ def _last_json(text):
 
 def test_bench_line_single_gpu():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--records", "8192", "--nt", "70", "--no-cpu-baseline",
-                        "--sample-rows", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+                        "--sample-rows", "2048", "--sample-rows-large", "4096"], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = _last_json(r.stdout)
     assert KEYS <= set(out) and out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0
@@ -32,7 +32,7 @@ def test_bench_line_single_gpu():
     assert out["roofline"]["launches_per_step"] == 2  # 70 timesteps = one launch of 64 + one of 6
     assert "workload" in out["config"] and "math" in out["config"]["workload"]
     # the other half of the metric and the other modes ride in the same line, each with its own roofline fraction
-    assert out["sampled_rows_per_s"] > 0 and out["sampled_rows_per_s_4x512"] > 0
+    assert out["sampled_rows_per_s"] > 0 and out["sampled_rows_per_s_4x512"] > 0 and out["sampled_rows_per_s_1M_rows"] > 0
     ex = out["extra"]
     for k in ("sampling_4x512", "sampling_4x1024"):
         assert ex[k]["T"] == 1000 and 0 < ex[k]["roofline_denoiser"]["frac"] < 1 and 0 < ex[k]["roofline_step"]["frac"] < 1
@@ -44,7 +44,7 @@ def test_bench_line_single_gpu():
 def test_bench_two_rank_rehearsal():
     env = dict(os.environ, MTK_BENCH_BACKEND="gloo", MTK_BENCH_CHECK="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "2", "--sample-rows", "1024"],
+                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "2", "--sample-rows", "1024", "--sample-rows-large", "0"],
                        cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
@@ -71,7 +71,7 @@ def test_bench_rccl_single_rank_rehearsal():
     (gloo cannot show that the RCCL calls and their stream semantics work; two ranks cannot share a card under RCCL)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     r = subprocess.run([sys.executable, "bench.py", "--rehearse-rccl", "--steps", "5", "--warmup", "2", "--records", "8192", "--nt", "70",
-                        "--no-cpu-baseline", "--sample-rows", "1024"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+                        "--no-cpu-baseline", "--sample-rows", "1024", "--sample-rows-large", "0"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _last_json(r.stdout)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["sampled_rows_per_s"] > 0

@@ -791,6 +791,18 @@ def test_out_of_range_timesteps_poison_their_rows():
         lm0, lg0 = d.mixed_loss_rows(x0.to(dev()), timestep=t.to(dev()), noise=eps.to(dev()), uniform=u.to(dev()))
         assert bool(lm[~ok].isnan().all()) and bool(lg[~ok].isnan().all())
         assert torch.equal(lm[ok], lm0[ok]) and torch.equal(lg[ok], lg0[ok])
+        # in-kernel noise, math "fast": those kernels poison in their own stores (no separate pass behind them)
+        d.rng = "philox"
+        lm, lg = d.mixed_loss_rows(x0.to(dev()), timestep=t_bad.to(dev()), seed=9)
+        lm0, lg0 = d.mixed_loss_rows(x0.to(dev()), timestep=t.to(dev()), seed=9)
+        assert bool(lm[~ok].isnan().all()) and bool(lg[~ok].isnan().all())
+        assert torch.equal(lm[ok], lm0[ok]) and torch.equal(lg[ok], lg0[ok]) and bool(torch.isfinite(lm0).all())
+        eng.set_math("fast")
+        xi = torch.empty((D, B), device=dev())
+        idx = torch.empty((C, B), dtype=torch.int32, device=dev())
+        eng.q_sample(x0.to(dev()), t_bad.to(dev()), None, None, xi, (1, B), idx, seed=9)
+        assert bool(xi[:, ~ok].isnan().all()) and bool(torch.isfinite(xi[:, ok]).all())
+        d.rng = "torch"
     # layered bf16 path (a shape the fused kernel does not cover)
     import midst_toolkit_amd as mtk
 
@@ -1495,6 +1507,55 @@ def test_cached_chain_graph_survives_workspace_growth(tag, precision):
     d2.sample(B1, torch.ones(1), seed=23, row0=0)
     d2.sample(B2, torch.ones(1), seed=23, row0=0)
     assert d2.engine().workspace_generation() == gen   # steady state: no reallocation, no re-capture
+
+
+@pytest.mark.parametrize("shape", ["M_4x1024", "ragged_2x256", "numeric_2x256", "catonly_2x256"])
+def test_denoiser_reads_the_chain_state(shape):
+    """mtk_mlp_forward_state (GMD:1406: the reference concatenates float(z) and the log-one-hot rows into a [B, D] matrix
+    every reverse step): the first block of the layered bf16 denoiser builds that operand from z / z_idx itself.  Same
+    rounding, same weights, same MFMA order as the route through the materialised matrix: the outputs must be identical
+    bit for bit - on a batch that is not a multiple of the tile, on one that spans two passes, and over whole chains
+    (eager and graph-replayed) whose step kernels no longer write any input matrix."""
+    import midst_toolkit_amd as mtk
+
+    K, Nn, layers = {"M_4x1024": ([10] * 10, 20, [1024] * 4), "ragged_2x256": ([3, 7, 10, 2, 12], 6, [256, 256]),
+                     "numeric_2x256": ([0], 24, [256, 256]), "catonly_2x256": ([4, 9, 16], 0, [256, 256])}[shape]
+    K = np.asarray(K)
+    C = 0 if int(K[0]) == 0 else len(K)
+    S = int(K.sum())
+    D, T = Nn + S, 30
+    torch.manual_seed(3)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(layers, 0.0))
+    net.precision = "bf16"
+    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev()).to(dev())
+    d.precision, d.rng = "bf16", "philox"
+    eng = d.engine()
+    assert eng.state_input_ok("bf16") and not eng.state_input_ok("fp32") and not eng.state_input_ok("bf16x3")
+    g = torch.Generator().manual_seed(1)
+    for B in (1000, 70000 if shape == "M_4x1024" else 3000):
+        z = (torch.randn((max(Nn, 1), B), generator=g, dtype=torch.float64) * 1.7).to(dev())
+        zi = torch.stack([torch.randint(0, int(k), (B,), generator=g) for k in (K if C else [1])]).to(torch.int32).to(dev())
+        x = torch.full((D, B), orc.LOG_TINY if hasattr(orc, "LOG_TINY") else float(np.log(np.float32(1e-30))), dtype=torch.float32, device=dev())
+        x[:Nn] = z[:Nn].float()
+        off = 0
+        for k in range(C):
+            x[Nn + off: Nn + off + int(K[k])].scatter_(0, zi[k].long().unsqueeze(0), 0.0)
+            off += int(K[k])
+        want = torch.empty((D, B), device=dev())
+        got = torch.full((D, B), float("nan"), device=dev())
+        eng.mlp_forward(x, 17, out=want, precision="bf16", x_strides=(1, B), out_strides=(1, B), B=B)
+        eng.mlp_forward_state(z, zi, 17, got, B, "bf16", out_strides=(1, B))
+        assert torch.equal(got, want), float((got - want).abs().max())
+    # whole chains: state route against the materialised route, eager and graph-replayed
+    B = 700
+    d.state_input = False
+    ref, _ = d.sample(B, torch.ones(1), seed=5, row0=0)
+    d.state_input = True
+    got, _ = d.sample(B, torch.ones(1), seed=5, row0=0)
+    assert torch.equal(got, ref) and bool(torch.isfinite(ref).all())
+    d.use_graph = True
+    rep, _ = d.sample(B, torch.ones(1), seed=5, row0=0)
+    assert torch.equal(rep, ref)
 
 
 def test_attack_feature_driver_reproduces_the_reference_loop():
