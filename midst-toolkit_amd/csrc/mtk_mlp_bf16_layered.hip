@@ -460,20 +460,36 @@ __global__ __launch_bounds__(512, 1) void k_first_state(FirstArgs g) {
     // (the launch is bound by them) - this way the stores drain under the next tile's operand build and MFMAs.
     double zpf[2][8];
     int ipf[kStateMaxC];
+    // A tile's state is loaded under the PREVIOUS tile's MFMAs and is complete in registers before that tile's output stores are
+    // issued (`landed`): vector memory operations retire in order, and the compiler waits with vmcnt(0) for any load that has
+    // stores around it - loads issued behind 128 KB of stores would make the operand build wait for the stores to drain, and the
+    // launch is bound by exactly those stores.  This way they drain under the next tile's build and MFMAs.  (Loads by inline asm
+    // with a hand-counted wait are not an option: the compiler, unaware that they land late, reuses their registers.)
+    // Branch-free: clamped addresses, every load issued (the host hands over valid pointers even for Nn = 0 or C = 0) - with
+    // loads under branches the compiler gives up counting altogether.
     auto prefetch = [&](int64_t slot) {
         const int64_t row = ((slot / g.nb_n) * 8 + xcd) * BM + r;
-        const bool live = row < g.M;
+        const int64_t rowc = row < g.M ? row : g.M - 1;
+        const int kz = g.Nn > 0 ? g.Nn - 1 : 0, kc = g.C > 0 ? g.C - 1 : 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = (half + 2 * q) * 8 + i;
-                zpf[q][i] = (live && k < g.Nn) ? g.z[(int64_t)k * g.ld + row] : 0.0;
+                zpf[q][i] = g.z[(int64_t)(k < kz ? k : kz) * g.ld + rowc];
             }
 #pragma unroll
-        for (int k = 0; k < kStateMaxC; ++k) ipf[k] = (live && k < g.C) ? g.z_idx[(int64_t)k * g.ld + row] : -1;
+        for (int k = 0; k < kStateMaxC; ++k) ipf[k] = g.z_idx[(int64_t)(k < kc ? k : kc) * g.ld + rowc];
     };
+    auto landed = [&]() {
+        asm volatile("" : "+v"(zpf[0][0]), "+v"(zpf[0][1]), "+v"(zpf[0][2]), "+v"(zpf[0][3]), "+v"(zpf[0][4]), "+v"(zpf[0][5]), "+v"(zpf[0][6]), "+v"(zpf[0][7]),
+                          "+v"(zpf[1][0]), "+v"(zpf[1][1]), "+v"(zpf[1][2]), "+v"(zpf[1][3]), "+v"(zpf[1][4]), "+v"(zpf[1][5]), "+v"(zpf[1][6]), "+v"(zpf[1][7]));
+        asm volatile("" : "+v"(ipf[0]), "+v"(ipf[1]), "+v"(ipf[2]), "+v"(ipf[3]), "+v"(ipf[4]), "+v"(ipf[5]), "+v"(ipf[6]), "+v"(ipf[7]),
+                          "+v"(ipf[8]), "+v"(ipf[9]), "+v"(ipf[10]), "+v"(ipf[11]), "+v"(ipf[12]), "+v"(ipf[13]), "+v"(ipf[14]), "+v"(ipf[15]));
+    };
+    static_assert(kStateMaxC == 16, "landed() names sixteen index registers");
     prefetch(wq);
+    landed();  // on EVERY path into the tile loop the state registers are asm results: no load is pending on them inside the loop
     // one-hot column offsets: a copy in LDS behind the two tiles (as scalar loads the compiler hoists all of them out of the
     // tile loop and spills them)
     int* offs = reinterpret_cast<int*>(lds + 4 * kTile);
@@ -513,8 +529,8 @@ __global__ __launch_bounds__(512, 1) void k_first_state(FirstArgs g) {
             };
 #pragma unroll
             for (int q = 0; q < 2; ++q) {  // the (partly) numeric pieces: float(z) rounded to bf16
-                const int p = half + 2 * q, k0 = p * 8;
-                if (p < np) {
+                const int p = half + 2 * q, k0 = p * 8;  // p <= 3: inside the first k-block
+                {
                     uint16_t v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -539,13 +555,19 @@ __global__ __launch_bounds__(512, 1) void k_first_state(FirstArgs g) {
             asm volatile("" ::: "memory");  // the fills above before the two-byte stores below (different access types)
             // the hot column of every categorical block: log(1) = 0.  The owner of the piece writes it, after its own fill
             // (LDS operations of one wave execute in order).
+            // Branch-free: a write that is not this thread's to make lands in a spare word behind the offsets.
+            // (indexed off the __shared__ array itself: through a selected pointer the store loses its address space and becomes
+            // a flat store with a vmcnt(0) behind it)
+            constexpr int spare = (4 * kTile + 96) / 2;
 #pragma unroll
-            for (int k = 0; k < kStateMaxC; ++k)
-                if (k < g.C && ipf[k] >= 0) {
-                    const int col = g.Nn + offs[k] + ipf[k];
-                    const int p = col >> 3;
-                    if ((p & 1) == half && p < np) *reinterpret_cast<volatile uint16_t*>(rowp + (p >> 3) * kTile + (((p & 7) ^ key_) * 16) + (col & 7) * 2) = 0;
-                }
+            for (int k = 0; k < kStateMaxC; ++k) {
+                const int col = g.Nn + offs[k < g.C ? k : 0] + ipf[k];
+                const int p = col >> 3;
+                const int dst = (r_ * 128 + (p >> 3) * kTile + (((p & 7) ^ key_) * 16) + (col & 7) * 2) / 2;
+                const bool mine = k < g.C && live && (p & 1) == half && p < np && ipf[k] >= 0;
+                gb_smem[mine ? dst : spare] = 0;
+            }
+            asm volatile("" ::: "memory");
         }
         // accumulators start from the bias (scalar loads, as in k_gemm_bf16)
         {
@@ -572,29 +594,44 @@ __global__ __launch_bounds__(512, 1) void k_first_state(FirstArgs g) {
         if (new_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's weight pieces have landed (first tile: nothing else is in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int kb = 0; kb < g.nkb; ++kb)
+        if (slot + wstride < slots) prefetch(slot + wstride);  // lands under the MFMAs below
+        {   // rolling fragment prefetch: the record fragment of the NEXT 32-record sub-tile (and, at a k-step's last sub-tile, the
+            // next k-step's weight fragments) is read while the two MFMAs of the current one issue - one spare record fragment
+            // and one spare pair of weight fragments instead of a second full set (the kernel has no registers for that)
+            auto rd_a = [&](int s, int q) -> bf16x8 {
+                const int kb = s >> 2, kp = (s & 3) * 2 + hh, ra = (wr * MW + q) * 32 + li;
+                return *reinterpret_cast<const bf16x8*>(lds + kb * kTile + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
+            };
+            auto rd_b = [&](int s, int q) -> bf16x8 {
+                const int kb = s >> 2, kp = (s & 3) * 2 + hh, rb = wc * WN + q * 32 + li;
+                return *reinterpret_cast<const bf16x8*>(ldsW + kb * kTile + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
+            };
+            const int ns = g.nkb * 4;
+            bf16x8 b0 = rd_b(0, 0), b1 = rd_b(0, 1), a = rd_a(0, 0), an, bn0 = b0, bn1 = b1;
+            for (int s = 0; s < ns; ++s) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 fa[MW], fb[NT];
-                const int kp = ks * 2 + hh;
-#pragma unroll
-                for (int q = 0; q < MW; ++q) {
-                    const int ra = (wr * MW + q) * 32 + li;
-                    fa[q] = *reinterpret_cast<const bf16x8*>(lds + kb * kTile + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
+                for (int mt = 0; mt < MW; ++mt) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (mt + 1 < MW) {
+                        an = rd_a(s, mt + 1);
+                    } else if (s + 1 < ns) {
+                        an = rd_a(s + 1, 0);
+                        bn0 = rd_b(s + 1, 0);
+                        bn1 = rd_b(s + 1, 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, acc[mt][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    a = an;
                 }
-#pragma unroll
-                for (int q = 0; q < NT; ++q) {
-                    const int rb = wc * WN + q * 32 + li;
-                    fb[q] = *reinterpret_cast<const bf16x8*>(ldsW + kb * kTile + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
-                }
-#pragma unroll
-                for (int mt = 0; mt < MW; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                b0 = bn0;
+                b1 = bn1;
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();  // every wave's fragment reads are done: the next tile's build may overwrite the record image
-        if (slot + wstride < slots) prefetch(slot + wstride);  // before this tile's stores (see above)
+        landed();         // the next tile's state is in registers before this tile's stores are issued (see prefetch)
         // epilogue: ReLU, bf16, v_permlane32_swap pairs the two half-pieces of a record's 16 bytes (see k_gemm_bf16)
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
@@ -939,7 +976,10 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
             if (folded && from_state) {  // the folded first block with its operand built in LDS from the state
                 FirstArgs f{};
                 f.M = M; f.nkb = kp0 / BK; f.Nn = c->Nn; f.C = c->C; f.D = c->D; f.off = c->d_off;
-                f.z = zst ? zst + r0 : nullptr; f.z_idx = zi ? zi + r0 : nullptr; f.ld = st_ld;
+                // the kernel's state loads are unconditional (clamped): with no numeric / no categorical columns they read the other array
+                f.z = zst && c->Nn > 0 ? zst + r0 : reinterpret_cast<const double*>(c->embf_l);
+                f.z_idx = zi && c->C > 0 ? zi + r0 : reinterpret_cast<const int32_t*>(c->embf_l);
+                f.ld = st_ld;
                 f.W = reinterpret_cast<const uint16_t*>(c->wb16_fold); f.w_ld = kp0;
                 f.bias = c->embf_l + (size_t)t_scalar * c->embf_ld;
                 ld = round_up(l.out_pad, BT);
