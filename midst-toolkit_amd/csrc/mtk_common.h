@@ -63,12 +63,28 @@ struct TrainState {
     // compute stream when that bucket of the gradient image is final (mtk_train_set_bucket_events); empty: no events
     std::vector<hipEvent_t> bucket_events;
     int bf16 = 0;  // mtk_train_set_precision: the iteration's GEMMs round their operands to bf16 (fp32 accumulate, fp32 master weights)
+    // bf16 mode stores what it multiplies as bf16 (half the bytes through the L2 -> CU pipe that bounds these GEMMs; the values
+    // were rounded to bf16 before every product anyway): saved activations, activation gradients, and a copy of the weight
+    // image that mtk_train_apply / attach / import keep in step with image 0
+    // and, because a tile whose reduction index is the slow one in memory costs twice the LDS-write work of one read along
+    // its rows, the TRANSPOSES the backward multiplies: W^T for the input gradients, act^T and dY^T for the weight gradients
+    // (written by the epilogue of the GEMM that produces act / dY).
+    uint16_t* w16 = nullptr;           // [n_img], layout of one image
+    uint16_t* w16t = nullptr;          // [n_img]: layer at w_off as [in_pad][out_pad] (hidden layers and head)
+    std::vector<uint16_t*> act16;      // act16[i] ~ act[i], row-major [cap16][out_pad]
+    std::vector<uint16_t*> act16t;     // act16t[i] = act16[i]^T, [out_pad][Mpad of the call]
+    uint16_t* dact16[2] = {nullptr, nullptr};
+    uint16_t* dact16t[2] = {nullptr, nullptr};
+    int64_t cap16 = 0;
     // time-embedding tables kept for the backward pass, [Tpad][tpad]
     float *sin_tab = nullptr, *z0_tab = nullptr, *e1_tab = nullptr, *demb = nullptr, *dtab = nullptr;
     int Tpad = 0;
     // activations for `cap` rows (a multiple of 128)
     int64_t cap = 0;
     int64_t fwd_rows = 0;          // rows of the last forward phase (mtk_train_backward must match it)
+    // xin / dout keep "rows >= B and padded features are zero" without a memset per iteration: they are zeroed when
+    // allocated, the kernels write rows < B only, and a call with fewer rows than the last one zeroes them again first
+    int64_t xin_rows = 0, dout_rows = 0;
     float* xin = nullptr;          // [round_up(D,128)][cap] column-major model input
     int32_t* xt_idx = nullptr;     // [C][cap]
     std::vector<float*> act;       // act[0] = proj output, act[i] = block i output, row-major [cap][out_pad]

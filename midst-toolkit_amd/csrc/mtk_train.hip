@@ -14,6 +14,7 @@
 // hardware fp32 atomic add into the zeroed gradient image).  The loss and its gradient come from
 // k_loss_grad (mtk_diffusion.hip); AdamW + EMA is one elementwise pass over the image.
 #include <math.h>
+#include <stdlib.h>
 
 #include "mtk_common.h"
 
@@ -47,7 +48,11 @@ struct G2 {
     // (rowsum_slab + z * M) with plain stores; k_reduce_splits then adds the slices in order.  Replaces the atomics.
     float* slab; int64_t slab_stride;
     float* rowsum_slab;
-    int bf16;                      // operands rounded to bf16 on their way from LDS to the MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+    int bf16;                      // operands rounded to bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate): k_gemm2b
+    // k_gemm2b only: A / B are bf16 arrays (lda / ldb in elements), C is a bf16 array (plain store: no slab, no atomics), mask is
+    int a16, b16, c16, mask16;
+    uint16_t* Ct; int64_t ct_ld;   // optional second copy of the result, transposed and bf16: Ct[n * ct_ld + m]
+    int tile64;                    // 64 x 64 tiles whatever the grid size (weight gradients split over the batch: see wgrad_chunk)
 };
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
@@ -252,16 +257,363 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 training GEMM (mtk_train_set_precision(MTK_PREC_BF16)), round 3.  k_gemm2<..., BF = true> above keeps fp32 tiles in
+// LDS and rounds at the fragment read.  At config 5's per-rank shape (2,048 rows, 4 x 1024) a 1024 x 1024 layer took 23 us
+// that way, 7 % of the bf16 peak, and the iteration was those GEMMs; rocprof and two rewrites of the loop (bf16 tiles in LDS,
+// 64 k per step; two k-steps of loads in flight) left the time where it was: the loop is bound by the bytes a CU pulls from
+// the L2 - 50 GB/s per CU, 12.5 TB/s chip-wide, for fp32 operands that are rounded to bf16 on arrival.  So in this mode the
+// operands are STORED as bf16 (saved activations, activation gradients, a bf16 copy of the weight image kept by the
+// optimizer kernel): half the bytes through the same pipe, and the same numbers - every one of them was rounded to bf16
+// before its product anyway.  Tiles are bf16 in LDS, [row][k] order whatever the source layout (a transposed source is
+// transposed by the LDS write), 64 k per step, one ds_read_b128 per fragment.  fp32 accumulation, fp32 gradient image,
+// split-K slabs, AdamW and EMA are unchanged.
+constexpr int KB2 = 64;          // k per step
+constexpr int PITCH2 = KB2 + 8;  // bf16 elements per LDS row: 144 B, 16-byte aligned, rows 36 dwords apart (conflict-free b128 reads)
+
+__device__ __forceinline__ unsigned g2_pack2(float a, float b) {
+    const __bf16 e[2] = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<const unsigned*>(e);
+}
+
+// SRC16 = false: fp32 source, rounded on the way into LDS.  SRC16 = true: bf16 source, copied.
+template <bool TR, int T, bool SRC16>
+struct TileMoverB;
+
+template <bool TR, int T>
+struct TileMoverB<TR, T, false> {
+    static constexpr int NLD = T * KB2 / 4 / 256;  // float4 per thread and k-step: 4 (T = 64) or 8 (T = 128)
+    static_assert(NLD == 4 || NLD == 8, "tile sizes 64 and 128");
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f r0, r1, r2, r3, r4, r5, r6, r7;
+    template <int Q>
+    __device__ __forceinline__ v4f& reg() {
+        if constexpr (Q == 0) return r0;
+        else if constexpr (Q == 1) return r1;
+        else if constexpr (Q == 2) return r2;
+        else if constexpr (Q == 3) return r3;
+        else if constexpr (Q == 4) return r4;
+        else if constexpr (Q == 5) return r5;
+        else if constexpr (Q == 6) return r6;
+        else return r7;
+    }
+    // !TR: thread (Q) -> row idx / 16, k = 4 (idx % 16).  TR (source [k][row]): registers 2j and 2j + 1 hold k = 2 kp and 2 kp + 1
+    // of the same four rows, so the LDS write packs the two k of each row into one dword.
+    template <int Q>
+    __device__ __forceinline__ void load_q(const void* src_, int64_t ld, int64_t row0, int k0, int kend, int tid) {
+        const float* src = reinterpret_cast<const float*>(src_);
+        if (!TR) {
+            const int idx = tid + 256 * Q, rr = idx >> 4, c = (idx & 15) * 4;
+            const bool ok = k0 + c < kend;  // K is a multiple of 32: a float4 is inside or outside as a whole
+            const v4f v = *reinterpret_cast<const v4f*>(src + (row0 + rr) * ld + (ok ? k0 + c : k0));
+            reg<Q>() = ok ? v : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
+            const int idx = tid + 256 * (Q >> 1), kp = idx / (T / 4), rq = (idx % (T / 4)) * 4, kk = 2 * kp + (Q & 1);
+            const bool ok = k0 + kk < kend;
+            const v4f v = *reinterpret_cast<const v4f*>(src + (int64_t)(ok ? k0 + kk : k0) * ld + row0 + rq);
+            reg<Q>() = ok ? v : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    template <int Q>
+    __device__ __forceinline__ void store_q(uint16_t* lds, int tid) {
+        if (!TR) {
+            const int idx = tid + 256 * Q, rr = idx >> 4, c = (idx & 15) * 4;
+            const v4f v = reg<Q>();
+            *reinterpret_cast<uint2*>(&lds[rr * PITCH2 + c]) = make_uint2(g2_pack2(v[0], v[1]), g2_pack2(v[2], v[3]));
+        } else if constexpr ((Q & 1) == 0) {
+            const int idx = tid + 256 * (Q >> 1), kp = idx / (T / 4), rq = (idx % (T / 4)) * 4;
+            const v4f lo = reg<Q>(), hi = reg<Q + 1>();
+            // the lanes of a write differ in their row group (4 rows = 144 dwords apart: two banks for sixteen lanes); lane i starts
+            // its four rows at row i mod 4, which spreads a write over eight banks (2-way: free for ds_write_b32)
+            const int rot = (rq >> 2) & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int jj = (j + rot) & 3;
+                const float a = mtk_pick4f(lo[0], lo[1], lo[2], lo[3], jj), b = mtk_pick4f(hi[0], hi[1], hi[2], hi[3], jj);
+                *reinterpret_cast<unsigned*>(&lds[(rq + jj) * PITCH2 + 2 * kp]) = g2_pack2(a, b);
+            }
+        }
+    }
+    template <int Q = 0>
+    __device__ __forceinline__ void load(const void* src, int64_t ld, int64_t row0, int k0, int kend, int tid) {
+        load_q<Q>(src, ld, row0, k0, kend, tid);
+        if constexpr (Q + 1 < NLD) load<Q + 1>(src, ld, row0, k0, kend, tid);
+    }
+    template <int Q = 0>
+    __device__ __forceinline__ void store(uint16_t* lds, int tid) {
+        store_q<Q>(lds, tid);
+        if constexpr (Q + 1 < NLD) store<Q + 1>(lds, tid);
+    }
+};
+
+template <bool TR, int T>
+struct TileMoverB<TR, T, true> {
+    static constexpr int NLD = T * KB2 / 8 / 256;  // 16-byte loads per thread and k-step: 2 (T = 64) or 4 (T = 128)
+    static_assert(NLD == 2 || NLD == 4, "tile sizes 64 and 128");
+    uint4 r0, r1, r2, r3;
+    template <int Q>
+    __device__ __forceinline__ uint4& reg() {
+        if constexpr (Q == 0) return r0;
+        else if constexpr (Q == 1) return r1;
+        else if constexpr (Q == 2) return r2;
+        else return r3;
+    }
+    // !TR: thread (Q) -> row idx / 8, k = 8 (idx % 8): a 16-byte load is a 16-byte LDS write.  TR (source [k][row]): a load is 8 rows
+    // of one k; registers 2j and 2j + 1 hold k = 2 kp and 2 kp + 1 of the same eight rows.
+    template <int Q>
+    __device__ __forceinline__ void load_q(const void* src_, int64_t ld, int64_t row0, int k0, int kend, int tid) {
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(src_);
+        if (!TR) {
+            const int idx = tid + 256 * Q, rr = idx >> 3, c = (idx & 7) * 8;
+            const bool ok = k0 + c < kend;
+            const uint4 v = *reinterpret_cast<const uint4*>(src + (row0 + rr) * ld + (ok ? k0 + c : k0));
+            reg<Q>() = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            const int idx = tid + 256 * (Q >> 1), kp = idx / (T / 8), rq = (idx % (T / 8)) * 8, kk = 2 * kp + (Q & 1);
+            const bool ok = k0 + kk < kend;
+            const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)(ok ? k0 + kk : k0) * ld + row0 + rq);
+            reg<Q>() = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    template <int Q>
+    __device__ __forceinline__ void store_q(uint16_t* lds, int tid) {
+        if (!TR) {
+            const int idx = tid + 256 * Q, rr = idx >> 3, c = (idx & 7) * 8;
+            *reinterpret_cast<uint4*>(&lds[rr * PITCH2 + c]) = reg<Q>();
+        } else if constexpr ((Q & 1) == 0) {
+            const int idx = tid + 256 * (Q >> 1), kp = idx / (T / 8), rq = (idx % (T / 8)) * 8;
+            const uint4 lo = reg<Q>(), hi = reg<Q + 1>();
+            // lanes of a write sit 8 rows (288 dwords, = 0 mod 32 banks) apart: lane i starts at row i mod 8 of its eight
+            const int rot = (rq >> 3) & 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jj = (j + rot) & 7;
+                const unsigned wl = mtk_pick4(lo.x, lo.y, lo.z, lo.w, jj >> 1), wh = mtk_pick4(hi.x, hi.y, hi.z, hi.w, jj >> 1);
+                const unsigned el = (jj & 1) ? (wl >> 16) : (wl & 0xffffu), eh = (jj & 1) ? (wh >> 16) : (wh & 0xffffu);
+                *reinterpret_cast<unsigned*>(&lds[(rq + jj) * PITCH2 + 2 * kp]) = el | (eh << 16);
+            }
+        }
+    }
+    template <int Q = 0>
+    __device__ __forceinline__ void load(const void* src, int64_t ld, int64_t row0, int k0, int kend, int tid) {
+        load_q<Q>(src, ld, row0, k0, kend, tid);
+        if constexpr (Q + 1 < NLD) load<Q + 1>(src, ld, row0, k0, kend, tid);
+    }
+    template <int Q = 0>
+    __device__ __forceinline__ void store(uint16_t* lds, int tid) {
+        store_q<Q>(lds, tid);
+        if constexpr (Q + 1 < NLD) store<Q + 1>(lds, tid);
+    }
+};
+
+template <bool AT, bool BT, int WT, bool A16, bool B16>
+__global__ __launch_bounds__(256) void k_gemm2b(G2 g) {
+    constexpr int T = 64 * WT;
+    constexpr int CP = 40;  // pitch (elements) of a wave's 32 x 32 staging tiles in the epilogue: 80-byte rows, 16-byte aligned
+    constexpr int kSmem = 2 * T * PITCH2 > 4 * 2 * 32 * CP ? 2 * T * PITCH2 : 4 * 2 * 32 * CP;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[kSmem];
+    uint16_t* const As = smem;
+    uint16_t* const Bs = smem + T * PITCH2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * T;
+    const int n0 = blockIdx.y * T;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+
+    f32x16 acc[WT][WT];
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < WT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const bool sum_rows = (g.rowsum != nullptr || g.rowsum_slab != nullptr) && blockIdx.y == 0 && wc == 0;  // wave-uniform
+    float rs[WT];
+#pragma unroll
+    for (int a = 0; a < WT; ++a) rs[a] = 0.0f;
+
+    TileMoverB<AT, T, A16> ma;
+    TileMoverB<BT, T, B16> mb;
+    ma.load(g.A, g.lda, m0, kbeg, kend, tid);
+    mb.load(g.B, g.ldb, n0, kbeg, kend, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += KB2) {
+        ma.store(As, tid);
+        mb.store(Bs, tid);
+        __syncthreads();
+        if (k0 + KB2 < kend) {  // next k-step's global loads fly while this one is multiplied
+            ma.load(g.A, g.lda, m0, k0 + KB2, kend, tid);
+            mb.load(g.B, g.ldb, n0, k0 + KB2, kend, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < KB2 / 16; ++s) {
+            bf16x8_t a[WT], b[WT];
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(&As[(wr * 32 * WT + mt * 32 + li) * PITCH2 + 16 * s + 8 * hh]);
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt) b[nt] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wc * 32 * WT + nt * 32 + li) * PITCH2 + 16 * s + 8 * hh]);
+            if (sum_rows) {
+#pragma unroll
+                for (int mt = 0; mt < WT; ++mt) {
+                    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) { t0 += (float)a[mt][j]; t1 += (float)a[mt][j + 1]; }
+                    rs[mt] += t0 + t1;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (sum_rows) {  // lanes l and l + 32 hold the two k-halves of row (lane & 31)
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt) {
+            const float tot = rs[mt] + __shfl_xor(rs[mt], 32);
+            if (hh == 0) {
+                if (g.rowsum_slab) g.rowsum_slab[(int64_t)blockIdx.z * g.M + m0 + wr * 32 * WT + mt * 32 + li] = tot;
+                else unsafeAtomicAdd(&g.rowsum[m0 + wr * 32 * WT + mt * 32 + li], tot);
+            }
+        }
+    }
+    // bf16 results (activations, activation gradients) leave through LDS: the MFMA layout gives a lane ONE column of the tile, so
+    // storing from it is a 2-byte store per element in 64-byte runs, the ReLU mask is read the same way, and the transposed copy
+    // goes out in 8-byte pieces a row apart (+3 us per copy, +5 us for the mask on a 2,048 x 1,024 result).  Each wave stages its
+    // own 32 x 32 sub-tiles (no workgroup barrier): mask tile in by 16-byte loads, results written over it in place (every
+    // element belongs to one lane) and, transposed, beside it; both leave as 16-byte stores.
+    if (g.c16 && g.c_cs == 1 && (!g.mask || (g.mask16 && g.neg_slope == 0.0f))) {
+        uint16_t* const cs = smem + wid * (2 * 32 * CP);
+        uint16_t* const cst = cs + 32 * CP;
+        uint16_t* const C16 = reinterpret_cast<uint16_t*>(g.C);
+        const uint16_t* const M16 = reinterpret_cast<const uint16_t*>(g.mask);
+        const int prow = lane >> 2, pch = (lane & 3) * 8;
+#pragma unroll
+        for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WT; ++nt) {
+                const int nb = n0 + wc * 32 * WT + nt * 32;  // wave-uniform (N is a multiple of 32 for these results)
+                if (nb >= g.N) continue;
+                const int64_t rb = m0 + wr * 32 * WT + mt * 32;
+                if (M16) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        *reinterpret_cast<uint4*>(&cs[(prow + 16 * i) * CP + pch]) =
+                            *reinterpret_cast<const uint4*>(M16 + (rb + prow + 16 * i) * g.m_rs + nb + pch);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+                const int n = nb + li;
+                const float bias = g.bias ? g.bias[n] : 0.0f;
+                unsigned tq[8];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int64_t row = rb + lr;
+                    float v = acc[mt][nt][r] + bias;
+                    if (g.emb) {
+                        const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
+                        v += g.emb[(int64_t)tr * g.emb_ld + n];
+                    }
+                    if (g.addend) v += g.addend[row * g.add_rs + n];
+                    if (g.relu == 2) v = v / (1.0f + expf(-v));
+                    else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                    if (M16) {
+                        const unsigned mbits = cs[lr * CP + li];
+                        v = (mbits != 0 && !(mbits & 0x8000u)) ? v : 0.0f;  // > 0 for a bf16 that is not a NaN (activations are not)
+                    }
+                    const __bf16 e = (__bf16)v;
+                    const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
+                    cs[lr * CP + li] = (uint16_t)bits;
+                    if (r & 1) tq[r >> 1] |= bits << 16; else tq[r >> 1] = bits;
+                }
+                if (g.Ct) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(&cst[li * CP + 8 * q + 4 * hh]) = make_uint2(tq[2 * q], tq[2 * q + 1]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pr = prow + 16 * i;
+                    *reinterpret_cast<uint4*>(C16 + (rb + pr) * g.c_rs + nb + pch) = *reinterpret_cast<const uint4*>(&cs[pr * CP + pch]);
+                    if (g.Ct) *reinterpret_cast<uint4*>(g.Ct + (int64_t)(nb + pr) * g.ct_ld + rb + pch) = *reinterpret_cast<const uint4*>(&cst[pr * CP + pch]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        return;
+    }
+    // epilogue: as k_gemm2 (C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
+    // c16: the result is an activation (or an activation gradient) stored as bf16; mask16: the saved activation is
+#pragma unroll
+    for (int mt = 0; mt < WT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) {
+            const int n = n0 + wc * 32 * WT + nt * 32 + li;
+            if (n >= g.N) continue;
+            const float bias = g.bias ? g.bias[n] : 0.0f;
+            unsigned tq[8];  // the 16 results as bf16 pairs, for the transposed copy
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 32 * WT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[mt][nt][r] + bias;
+                if (g.emb) {
+                    const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
+                    v += g.emb[(int64_t)tr * g.emb_ld + n];
+                }
+                if (g.addend) v += g.addend[row * g.add_rs + n];
+                if (g.relu == 2) v = v / (1.0f + expf(-v));
+                else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                if (g.mask) {
+                    bool pos;
+                    if (g.mask16) {
+                        const uint16_t mbits = reinterpret_cast<const uint16_t*>(g.mask)[row * g.m_rs + n];
+                        pos = mbits != 0 && !(mbits & 0x8000u);  // > 0 for a bf16 that is not a NaN (activations are not)
+                    } else {
+                        pos = g.mask[row * g.m_rs + n] > 0.0f;
+                    }
+                    v = pos ? v : g.neg_slope * v;
+                }
+                if (g.c16) {
+                    const __bf16 e = (__bf16)v;
+                    const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
+                    reinterpret_cast<uint16_t*>(g.C)[row * g.c_rs + (int64_t)n * g.c_cs] = (uint16_t)bits;
+                    if (r & 1) tq[r >> 1] |= bits << 16; else tq[r >> 1] = bits;
+                } else {
+                    float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
+                    if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
+                }
+            }
+            if (g.c16 && g.Ct) {  // registers 4 q .. 4 q + 3 are rows 8 q + 4 hh .. + 3: eight contiguous bytes of column n of C^T
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = m0 + wr * 32 * WT + mt * 32 + 8 * q + 4 * hh;
+                    *reinterpret_cast<uint2*>(&g.Ct[(int64_t)n * g.ct_ld + row]) = make_uint2(tq[2 * q], tq[2 * q + 1]);
+                }
+            }
+        }
+}
+
+template <bool AT, bool BT, int WT>
+void launch_b(const G2& g, dim3 grid, hipStream_t s) {
+    if (g.a16 && g.b16) hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, true, true>), grid, dim3(256), 0, s, g);
+    else if (g.a16) hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, true, false>), grid, dim3(256), 0, s, g);
+    else if (g.b16) hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, false, false>), grid, dim3(256), 0, s, g);
+}
+
 template <bool AT, bool BT>
 int launch(const G2& g, hipStream_t s) {
     const int splits = (g.K + g.kchunk - 1) / g.kchunk;
     const int64_t wg128 = (int64_t)(g.M / TM) * ((g.N + TN - 1) / TN) * splits;
     const dim3 g128((unsigned)(g.M / 128), (unsigned)((g.N + 127) / 128), (unsigned)splits), g64((unsigned)(g.M / 64), (unsigned)((g.N + 63) / 64), (unsigned)splits);
-    if (wg128 >= 512) {
-        if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 2, true>), g128, dim3(256), 0, s, g);
+    static const bool old_bf = getenv("MTK_TRAIN_BF16_OLD") != nullptr;  // A/B: the round-2 bf16 instantiation (fp32 tiles in LDS)
+    if (wg128 >= 512 && !g.tile64) {
+        if (g.bf16 && !old_bf) launch_b<AT, BT, 2>(g, g128, s);
+        else if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 2, true>), g128, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_gemm2<AT, BT, 2, false>), g128, dim3(256), 0, s, g);
     } else {
-        if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 1, true>), g64, dim3(256), 0, s, g);
+        if (g.bf16 && !old_bf) launch_b<AT, BT, 1>(g, g64, s);
+        else if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 1, true>), g64, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_gemm2<AT, BT, 1, false>), g64, dim3(256), 0, s, g);
     }
     MTK_HIP(hipGetLastError());
@@ -285,11 +637,16 @@ __global__ __launch_bounds__(256) void k_rowsum_cm(const float* dy, int64_t ld, 
 // d emb[t[row]][:] += d act0[row][:]   (the time embedding is added to the proj output, MODEL:608-611)
 // One wave per row (blockDim = 64 x 4): the row's timestep is a wave-uniform load and the lanes walk its columns — no
 // 64-bit division per element (the flat-index version spent 51 us on 4096 x 128 values).
-__global__ __launch_bounds__(256) void k_scatter_emb(const float* dact, int64_t ld, const int64_t* t, int64_t rows, int n, float* demb, int emb_ld, int T) {
+template <bool S16>  // S16: d act0 is stored as bf16 (bf16 training mode)
+__device__ __forceinline__ float dact_at(const void* dact, int64_t i) {
+    if (S16) return __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(dact)[i] << 16);
+    return reinterpret_cast<const float*>(dact)[i];
+}
+template <bool S16>
+__global__ __launch_bounds__(256) void k_scatter_emb(const void* dact, int64_t ld, const int64_t* t, int64_t rows, int n, float* demb, int emb_ld, int T) {
     for (int64_t r = (int64_t)blockIdx.x * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.x * 4) {
         float* dst = demb + (int64_t)mtk_tclamp(t[r], T) * emb_ld;
-        const float* src = dact + r * ld;
-        for (int c = threadIdx.x; c < n; c += 64) unsafeAtomicAdd(&dst[c], src[c]);
+        for (int c = threadIdx.x; c < n; c += 64) unsafeAtomicAdd(&dst[c], dact_at<S16>(dact, r * ld + c));
     }
 }
 // dst[i] = sum over the `splits` slices of a slab region, slices added in index order (run-to-run identical), 4 floats per
@@ -326,15 +683,20 @@ __global__ __launch_bounds__(256) void k_reduce_splits(ReduceSegs r) {
 // Deterministic scatter-add of d act0 into the [T, dim_t] time-embedding gradient: 64-bit fixed-point integer atomics
 // (integer addition is associative, so the result does not depend on the order the rows arrive in), 2^-36 resolution.
 constexpr double kFixScale = 68719476736.0;  // 2^36: |sum| < 1.3e8, resolution 1.5e-11
-__global__ __launch_bounds__(256) void k_scatter_emb_fixed(const float* dact, int64_t ld, const int64_t* t, int64_t rows, int n, long long* acc, int emb_ld, int T) {
+template <bool S16>
+__global__ __launch_bounds__(256) void k_scatter_emb_fixed(const void* dact, int64_t ld, const int64_t* t, int64_t rows, int n, long long* acc, int emb_ld, int T) {
     for (int64_t r = (int64_t)blockIdx.x * 4 + threadIdx.y; r < rows; r += (int64_t)gridDim.x * 4) {
         long long* dst = acc + (int64_t)mtk_tclamp(t[r], T) * emb_ld;
-        const float* src = dact + r * ld;
-        for (int c = threadIdx.x; c < n; c += 64) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[c]), (unsigned long long)__double2ll_rn((double)src[c] * kFixScale));
+        for (int c = threadIdx.x; c < n; c += 64)
+            atomicAdd(reinterpret_cast<unsigned long long*>(&dst[c]), (unsigned long long)__double2ll_rn((double)dact_at<S16>(dact, r * ld + c) * kFixScale));
     }
 }
-__global__ void k_fixed_to_float(const long long* acc, float* dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (float)((double)acc[i] / kFixScale);
+// ... and leaves the accumulator zero for the next iteration (it is zeroed once, when allocated)
+__global__ void k_fixed_to_float(long long* acc, float* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        dst[i] = (float)((double)acc[i] / kFixScale);
+        acc[i] = 0;
+    }
 }
 __global__ void k_silu(const float* z, float* y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -366,6 +728,7 @@ __global__ void k_sin_tab(float* dst, int Tpad, int ld, int T, int dim, const fl
 
 // torch.optim.AdamW (single-tensor path) followed by the EMA of TRAINER:138-155, one pass over the image.
 struct AdamArgs {
+    uint16_t* p16;  // optional bf16 copy of the updated weights (bf16 training mode)
     float *p, *m, *v, *ema;
     const float* g;
     int64_t n;
@@ -386,6 +749,10 @@ __global__ __launch_bounds__(256) void k_adamw_ema(AdamArgs a) {
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
         p = p - a.step_size * (m / denom);
         a.p[i] = p;
+        if (a.p16) {
+            const __bf16 e = (__bf16)p;
+            a.p16[i] = *reinterpret_cast<const uint16_t*>(&e);
+        }
         a.m[i] = m;
         a.v[i] = v;
         a.ema[i] = a.ema[i] * a.ema_rate + a.ema_c * p;
@@ -404,6 +771,43 @@ __global__ void k_pad(float* dst, int ld, const float* src, int rows, int cols) 
         dst[(i / cols) * ld + (i % cols)] = src[i];
 }
 
+__global__ void k_f32_to_bf16(const float* src, uint16_t* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const __bf16 e = (__bf16)src[i];
+        dst[i] = *reinterpret_cast<const uint16_t*>(&e);
+    }
+}
+
+// bf16 W^T of the layers the backward takes input gradients through: 64 x 64 tiles through LDS, one launch for all of them
+constexpr int kMaxTr = 40;
+struct TrSegs {
+    int64_t off[kMaxTr];  // element offset of the layer's weights in an image
+    int rows[kMaxTr], cols[kMaxTr];  // out_pad, in_pad (multiples of 32)
+    int tile0[kMaxTr + 1];           // first tile of each layer in the flat tile list
+    int n;
+};
+__global__ __launch_bounds__(256) void k_w16_transpose(const float* img, uint16_t* w16t, TrSegs sg) {
+    __shared__ uint16_t tile[32][34];
+    const int total = sg.tile0[sg.n];
+    for (int tix = blockIdx.x; tix < total; tix += gridDim.x) {
+        int l = 0;
+        while (tix >= sg.tile0[l + 1]) ++l;
+        const int tpr = sg.cols[l] / 32, tl = tix - sg.tile0[l], r0 = (tl / tpr) * 32, c0 = (tl % tpr) * 32;
+        const float* src = img + sg.off[l];
+        uint16_t* dst = w16t + sg.off[l];
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 e = (__bf16)src[(int64_t)(r0 + ty + 8 * j) * sg.cols[l] + c0 + tx];
+            tile[ty + 8 * j][tx] = *reinterpret_cast<const uint16_t*>(&e);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(int64_t)(c0 + ty + 8 * j) * sg.rows[l] + r0 + tx] = tile[tx][ty + 8 * j];
+        __syncthreads();
+    }
+}
+
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
@@ -420,6 +824,12 @@ void free_acts(TrainState& tr) {
     for (auto& p : tr.act) fr(p);
     tr.act.clear();
     tr.cap = 0;
+    for (auto& p : tr.act16) fr(p);
+    tr.act16.clear();
+    for (auto& p : tr.act16t) fr(p);
+    tr.act16t.clear();
+    fr(tr.dact16[0]); fr(tr.dact16[1]); fr(tr.dact16t[0]); fr(tr.dact16t[1]);
+    tr.cap16 = 0;
 }
 
 int kchunk_for(int64_t K, int tiles);
@@ -441,6 +851,9 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     MTK_HIP(hipMalloc(&tr.xt_idx, sizeof(int32_t) * (size_t)(c->C > 0 ? c->C : 1) * Mpad));
     MTK_HIP(hipMalloc(&tr.out, sizeof(float) * (size_t)Dp * Mpad));
     MTK_HIP(hipMalloc(&tr.dout, sizeof(float) * (size_t)Dp * Mpad));
+    MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * Mpad, s));
+    MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * Mpad, s));
+    tr.xin_rows = tr.dout_rows = 0;
     for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact[i], sizeof(float) * (size_t)Mpad * maxpad));
     tr.act.assign(1 + c->blocks.size(), nullptr);
     MTK_HIP(hipMalloc(&tr.act[0], sizeof(float) * (size_t)Mpad * c->proj.out_pad));
@@ -467,6 +880,64 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     tr.slab_elems = need;
     tr.slab_rs_elems = need_rs;
     tr.cap = Mpad;
+    return MTK_OK;
+}
+
+// bf16 mode: the bf16 activation / activation-gradient buffers and the bf16 weight copy (allocated on first use of the mode)
+int refresh_w16t(mtk_ctx* c, hipStream_t s) {
+    TrainState& tr = c->train;
+    if (!tr.w16t) return MTK_OK;
+    TrSegs sg;
+    sg.n = 0;
+    sg.tile0[0] = 0;
+    auto add = [&](const MlpLayer& l) {
+        sg.off[sg.n] = l.w32 - tr.state; sg.rows[sg.n] = l.out_pad; sg.cols[sg.n] = l.in_pad;
+        sg.tile0[sg.n + 1] = sg.tile0[sg.n] + (l.out_pad / 32) * (l.in_pad / 32);
+        ++sg.n;
+    };
+    if ((int)c->blocks.size() + 1 > kMaxTr) MTK_FAIL(MTK_ERR_UNSUPPORTED, "bf16 training: more than %d layers", kMaxTr - 1);
+    for (auto& l : c->blocks) add(l);
+    add(c->head);
+    const int total = sg.tile0[sg.n];
+    hipLaunchKernelGGL(k_w16_transpose, dim3((unsigned)(total < 4096 ? total : 4096)), dim3(256), 0, s, tr.state, tr.w16t, sg);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+int refresh_w16(mtk_ctx* c, hipStream_t s) {
+    TrainState& tr = c->train;
+    if (!tr.w16) return MTK_OK;
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3(1024), dim3(256), 0, s, tr.state, tr.w16, (int64_t)tr.n_img);
+    MTK_HIP(hipGetLastError());
+    return refresh_w16t(c, s);
+}
+int ensure_acts16(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
+    TrainState& tr = c->train;
+    if (!tr.w16) {
+        MTK_HIP(hipStreamSynchronize(s));
+        MTK_HIP(hipMalloc(&tr.w16, sizeof(uint16_t) * tr.n_img));
+        MTK_HIP(hipMalloc(&tr.w16t, sizeof(uint16_t) * tr.n_img));
+        ++c->ws_gen;
+        const int rc = refresh_w16(c, s);
+        if (rc) return rc;
+    }
+    if (Mpad <= tr.cap16) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    auto fr = [](uint16_t*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    for (auto& p : tr.act16) fr(p);
+    for (auto& p : tr.act16t) fr(p);
+    fr(tr.dact16[0]); fr(tr.dact16[1]); fr(tr.dact16t[0]); fr(tr.dact16t[1]);
+    ++c->ws_gen;
+    int maxpad = c->proj.out_pad;
+    for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
+    tr.act16.assign(1 + c->blocks.size(), nullptr);
+    MTK_HIP(hipMalloc(&tr.act16[0], sizeof(uint16_t) * (size_t)Mpad * c->proj.out_pad));
+    for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act16[1 + i], sizeof(uint16_t) * (size_t)Mpad * c->blocks[i].out_pad));
+    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact16[i], sizeof(uint16_t) * (size_t)Mpad * maxpad));
+    tr.act16t.assign(1 + c->blocks.size(), nullptr);
+    MTK_HIP(hipMalloc(&tr.act16t[0], sizeof(uint16_t) * (size_t)Mpad * c->proj.out_pad));
+    for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act16t[1 + i], sizeof(uint16_t) * (size_t)Mpad * c->blocks[i].out_pad));
+    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact16t[i], sizeof(uint16_t) * (size_t)Mpad * maxpad));
+    tr.cap16 = Mpad;
     return MTK_OK;
 }
 
@@ -500,7 +971,9 @@ int kchunk_for(int64_t K, int tiles) {
 int mtk_reserve_train(mtk_ctx* c, int64_t rows, hipStream_t s) {  // mtk_ctx_reserve: activations of a training iteration
     if (!c->train.attached || rows <= 0) return MTK_OK;
     if (rows > (1 << 22)) rows = 1 << 22;
-    return ensure_acts(c, (rows + TM - 1) / TM * TM, s);
+    const int rc = ensure_acts(c, (rows + TM - 1) / TM * TM, s);
+    if (rc || !c->train.bf16) return rc;
+    return ensure_acts16(c, (rows + TM - 1) / TM * TM, s);
 }
 
 void mtk_free_train(mtk_ctx* c) {
@@ -510,6 +983,10 @@ void mtk_free_train(mtk_ctx* c) {
     if (tr.demb_fix) (void)hipFree(tr.demb_fix);
     tr.demb_fix = nullptr;
     free_acts(tr);
+    if (tr.w16) (void)hipFree(tr.w16);
+    if (tr.w16t) (void)hipFree(tr.w16t);
+    tr.w16 = nullptr;
+    tr.w16t = nullptr;
     tr.layers.clear();
     tr.attached = false;
     tr.state = nullptr;
@@ -573,6 +1050,7 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     MTK_HIP(hipMalloc(&tr.demb, tb));
     MTK_HIP(hipMalloc(&tr.dtab, tb));
     MTK_HIP(hipMalloc(&tr.demb_fix, sizeof(long long) * (size_t)tr.Tpad * tp));
+    MTK_HIP(hipMemsetAsync(tr.demb_fix, 0, sizeof(long long) * (size_t)tr.Tpad * tp, s));
     float* d_freq = nullptr;
     MTK_HIP(hipMalloc(&d_freq, sizeof(float) * (c->dim_t / 2)));
     MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (c->dim_t / 2), hipMemcpyHostToDevice, s));
@@ -611,9 +1089,27 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     const size_t n = tr.n_img;
     float* grads = tr.state + n;
 
+    // bf16 mode with bf16-stored operands (see TrainState::w16); MTK_TRAIN_BF16_OLD keeps the fp32-stored operands
+    static const bool old_bf = getenv("MTK_TRAIN_BF16_OLD") != nullptr;
+    const bool st16 = tr.bf16 && !old_bf;
+    if (st16 && (rc = ensure_acts16(c, Mpad, s))) return rc;
+    auto f16 = [](const uint16_t* p) { return reinterpret_cast<const float*>(p); };
+    auto w_of = [&](const MlpLayer& l) { return st16 ? f16(tr.w16 + (l.w32 - tr.state)) : (const float*)l.w32; };
+    auto act_of = [&](size_t i) { return st16 ? f16(tr.act16[i]) : (const float*)tr.act[i]; };
+    auto dact_of = [&](int i) { return st16 ? f16(tr.dact16[i]) : (const float*)tr.dact[i]; };
+    auto wt_of = [&](const MlpLayer& l) { return f16(tr.w16t + (l.w32 - tr.state)); };  // st16 only: [in_pad][out_pad]
+    // Reduction chunk of a weight-gradient GEMM [M x N] over K rows.  A split costs a partial tile written to the slab and read back
+    // by k_reduce_splits, and a 128 x 128 tile with 8 splits of a 2,048-row batch runs 4 k-steps per workgroup: with bf16 operands the
+    // 64 x 64 tiles fill the chip with a quarter of the splits (1024 x 1024 over 2,048 rows: 23 -> 14 us, k_reduce_splits 20 -> 8 us).
+    auto wgrad_chunk = [&](G2& g) {
+        const int t128 = (g.M / TM) * ((g.N + TN - 1) / TN), t64 = (g.M / 64) * ((g.N + 63) / 64);
+        g.tile64 = st16 ? 1 : 0;
+        g.kchunk = kchunk_for(g.K, st16 ? t64 : t128);
+    };
     if (do_fwd) {
     tr.fwd_rows = B;
-    MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * ld, s));
+    if (B < tr.xin_rows) MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * ld, s));
+    tr.xin_rows = B;
 
     // ---- forward, activations kept
     // xt_idx is addressed [C][B] by the kernels (row stride B)
@@ -622,8 +1118,9 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         G2 g{};
         g.bf16 = tr.bf16;
         g.M = (int)Mpad; g.N = c->proj.out_pad; g.K = c->proj.in_pad; g.kchunk = g.K;
-        g.A = tr.xin; g.lda = ld; g.B = c->proj.w32; g.ldb = c->proj.in_pad;
-        g.C = tr.act[0]; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
+        g.A = tr.xin; g.lda = ld; g.B = w_of(c->proj); g.ldb = c->proj.in_pad; g.b16 = st16;
+        g.C = const_cast<float*>(act_of(0)); g.c16 = st16; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
+        if (st16) { g.Ct = tr.act16t[0]; g.ct_ld = Mpad; }
         g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t; g.rows_valid = B; g.T = c->T;
         if ((rc = launch<true, false>(g, s))) return rc;
     }
@@ -632,8 +1129,9 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         G2 g{};
         g.bf16 = tr.bf16;
         g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
-        g.A = tr.act[i]; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
-        g.C = tr.act[i + 1]; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32; g.relu = 1;
+        g.A = act_of(i); g.a16 = st16; g.lda = l.in_pad; g.B = w_of(l); g.b16 = st16; g.ldb = l.in_pad;
+        g.C = const_cast<float*>(act_of(i + 1)); g.c16 = st16; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32; g.relu = 1;
+        if (st16) { g.Ct = tr.act16t[i + 1]; g.ct_ld = Mpad; }
         if ((rc = launch<false, false>(g, s))) return rc;
     }
     {
@@ -641,17 +1139,23 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         G2 g{};
         g.bf16 = tr.bf16;
         g.M = (int)Mpad; g.N = l.out; g.K = l.in_pad; g.kchunk = g.K;
-        g.A = tr.act.back(); g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
+        g.A = act_of(c->blocks.size()); g.a16 = st16; g.lda = l.in_pad; g.B = w_of(l); g.b16 = st16; g.ldb = l.in_pad;
         g.C = tr.out; g.c_rs = 1; g.c_cs = ld; g.bias = l.b32;
         if ((rc = launch<false, false>(g, s))) return rc;
     }
     }
     if (!do_bwd) {  // losses only (the gradient scratch it also fills is rewritten by the backward phase)
+        if (B > tr.dout_rows) tr.dout_rows = B;
         return mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout, 0.0, 0.0, nullptr, seed, row0, s);
     }
-    MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
-    MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
-    MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
+    // deterministic mode stores every element of the gradient image (the split-batch partials are summed into it, the head
+    // bias row sums cover its padding) and of d emb; the atomic mode accumulates into both
+    if (!tr.deterministic) {
+        MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
+        MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
+    }
+    if (B < tr.dout_rows) MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
+    tr.dout_rows = B;
     // ---- loss and d loss / d out (column-major, rows >= B and features >= D stay zero)
     if ((rc = mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout,
                                    w_multi, w_gauss, w_dev, seed, row0, s)))
@@ -713,60 +1217,66 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         TrainLayerRef& r = ref_of(&l);
         G2 g{};
         g.bf16 = tr.bf16;
-        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
-        g.A = tr.dout; g.lda = ld; g.B = tr.act.back(); g.ldb = l.in_pad;
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
+        g.A = tr.dout; g.lda = ld; g.B = act_of(c->blocks.size()); g.b16 = st16; g.ldb = l.in_pad;
+        if (st16) { g.B = f16(tr.act16t.back()); g.ldb = Mpad; }
         g.c_rs = l.in_pad; g.c_cs = 1;
-        if ((rc = wgrad(g, [&](const G2& q) { return launch<false, true>(q, s); }, grads + r.w_off, nullptr))) return rc;
-        hipLaunchKernelGGL(k_rowsum_cm, dim3(l.out), dim3(256), 0, s, tr.dout, ld, Mpad, grads + r.b_off);
+        // db = row sums of dout [out_pad][Mpad] ride along (rows >= out are zero: the padding of the bias gradient is written too)
+        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<false, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
         if ((rc = bucket_done())) return rc;
         G2 d{};
         d.bf16 = tr.bf16;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
-        d.A = tr.dout; d.lda = ld; d.B = l.w32; d.ldb = l.in_pad;
-        d.C = tr.dact[0]; d.c_rs = l.in_pad; d.c_cs = 1;
-        if (!c->blocks.empty()) { d.mask = tr.act.back(); d.m_rs = l.in_pad; }
-        if ((rc = launch<true, true>(d, s))) return rc;
+        d.A = tr.dout; d.lda = ld; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
+        d.C = const_cast<float*>(dact_of(0)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
+        if (!c->blocks.empty()) { d.mask = act_of(c->blocks.size()); d.mask16 = st16; d.m_rs = l.in_pad; }
+        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[0]; d.ct_ld = Mpad; }
+        if ((rc = st16 ? launch<true, false>(d, s) : launch<true, true>(d, s))) return rc;
     }
     int cur = 0;
     for (int i = (int)c->blocks.size() - 1; i >= 0; --i) {
         MlpLayer& l = c->blocks[i];
         TrainLayerRef& r = ref_of(&l);
-        const float* dy = tr.dact[cur];  // [Mpad][out_pad], already masked by this layer's ReLU
+        const float* dy = dact_of(cur);  // [Mpad][out_pad], already masked by this layer's ReLU
         G2 g{};
         g.bf16 = tr.bf16;
-        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
-        g.A = dy; g.lda = l.out_pad; g.B = tr.act[i]; g.ldb = l.in_pad;
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
+        g.A = dy; g.a16 = st16; g.lda = l.out_pad; g.B = act_of(i); g.b16 = st16; g.ldb = l.in_pad;
+        if (st16) { g.A = f16(tr.dact16t[cur]); g.lda = Mpad; g.B = f16(tr.act16t[i]); g.ldb = Mpad; }
         g.c_rs = l.in_pad; g.c_cs = 1;
         // db[o] = sum_m dy[m][o] rides along
-        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
         if ((rc = bucket_done())) return rc;
         G2 d{};
         d.bf16 = tr.bf16;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
-        d.A = dy; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
-        d.C = tr.dact[cur ^ 1]; d.c_rs = l.in_pad; d.c_cs = 1;
-        if (i > 0) { d.mask = tr.act[i]; d.m_rs = l.in_pad; }  // act[0] (proj + emb) has no ReLU
-        if ((rc = launch<false, true>(d, s))) return rc;
+        d.A = dy; d.a16 = st16; d.lda = l.out_pad; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
+        d.C = const_cast<float*>(dact_of(cur ^ 1)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
+        if (i > 0) { d.mask = act_of(i); d.mask16 = st16; d.m_rs = l.in_pad; }  // act[0] (proj + emb) has no ReLU
+        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[cur ^ 1]; d.ct_ld = Mpad; }
+        if ((rc = st16 ? launch<false, false>(d, s) : launch<false, true>(d, s))) return rc;
         cur ^= 1;
     }
     {   // proj: dW[o][k] = sum_m dact0[m][o] xin[k][m];  db;  d emb table
         MlpLayer& l = c->proj;
         TrainLayerRef& r = ref_of(&l);
-        const float* dy = tr.dact[cur];  // [Mpad][proj.out_pad]
+        const float* dy = dact_of(cur);  // [Mpad][proj.out_pad]
         G2 g{};
         g.bf16 = tr.bf16;
-        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = kchunk_for(Mpad, (l.out_pad / TM) * ((l.in_pad + TN - 1) / TN));
-        g.A = dy; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
+        g.A = dy; g.a16 = st16; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
+        if (st16) { g.A = f16(tr.dact16t[cur]); g.lda = Mpad; }
         g.c_rs = l.in_pad; g.c_cs = 1;
-        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
         if ((rc = bucket_done())) return rc;
         if (tr.deterministic) {
             const int64_t ne = (int64_t)tr.Tpad * c->emb_ld;
-            MTK_HIP(hipMemsetAsync(tr.demb_fix, 0, sizeof(long long) * (size_t)ne, s));
-            hipLaunchKernelGGL(k_scatter_emb_fixed, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
+            if (st16) hipLaunchKernelGGL(k_scatter_emb_fixed<true>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
+            else hipLaunchKernelGGL(k_scatter_emb_fixed<false>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
             hipLaunchKernelGGL(k_fixed_to_float, dim3(256), dim3(256), 0, s, tr.demb_fix, tr.demb, ne);
         } else {
-            hipLaunchKernelGGL(k_scatter_emb, dim3(1024), dim3(64, 4), 0, s, dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
+            if (st16) hipLaunchKernelGGL(k_scatter_emb<true>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
+            else hipLaunchKernelGGL(k_scatter_emb<false>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
         }
     }
     {   // time-embedding MLP over the T-row table
@@ -883,6 +1393,7 @@ extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, doubl
     TrainState& tr = c->train;
     const size_t n = tr.n_img;
     AdamArgs a;
+    a.p16 = tr.w16;
     a.p = tr.state; a.g = tr.state + n; a.m = tr.state + 2 * n; a.v = tr.state + 3 * n; a.ema = tr.state + 4 * n;
     a.n = (int64_t)n;
     a.decay = (float)(1.0 - lr * weight_decay);
@@ -896,6 +1407,8 @@ extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, doubl
     a.ema_c = (float)(1.0 - ema_rate);
     hipLaunchKernelGGL(k_adamw_ema, dim3(1024), dim3(256), 0, s, a);
     MTK_HIP(hipGetLastError());
+    const int rc = refresh_w16t(c, s);
+    if (rc) return rc;
     return refresh_emb(c, s);
 }
 
@@ -932,7 +1445,11 @@ extern "C" int mtk_train_import(mtk_ctx* c, int image, const float* const* W, co
         hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, img + tr.layers[i].b_off, l.out_pad, b[i], 1, l.out);
     }
     MTK_HIP(hipGetLastError());
-    if (image == 0) return refresh_emb(c, s);
+    if (image == 0) {
+        const int rc = refresh_w16(c, s);
+        if (rc) return rc;
+        return refresh_emb(c, s);
+    }
     return MTK_OK;
 }
 

@@ -193,6 +193,35 @@ def test_bf16_training_gradients(B, layers):
         assert float((got32[k].double() - want[k].double()).norm()) <= 2e-4 * float(want[k].double().norm()) + 1e-9
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_iteration_needs_no_memset_of_its_buffers(precision):
+    """The deterministic iteration stores every element of the gradient image (so it is not zeroed per step) and keeps the rows
+    past the batch of its input / output-gradient buffers zero by tracking the rows written (zeroed only when a batch is smaller
+    than the one before): a gradient image filled with NaN beforehand comes out finite and equal to a clean run, and a small
+    batch after a big one equals the small batch alone."""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[256, 256])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    eng.train_set_precision(precision)
+    small, big = big_batch(c, 300), big_batch(c, 1500)
+    def run(batch):
+        B = batch[0].shape[0]
+        lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+        eng.train_step(*(v.to(dev()) for v in batch), 1.0 / B, lm, lg)
+        return tr.state[1].clone(), lm.clone(), lg.clone()
+    clean = run(small)
+    tr.state[1].fill_(float("nan"))
+    again = run(small)
+    assert bool(torch.isfinite(again[0]).all())
+    assert all(torch.equal(a, b) for a, b in zip(clean, again))
+    run(big)
+    eng.train_forward(*(v.to(dev()) for v in big), torch.empty(1500, device=dev()), torch.empty(1500, device=dev()))
+    after_big = run(small)
+    assert all(torch.equal(a, b) for a, b in zip(clean, after_big))
+
+
 def test_bf16_training_berka_run():
     """The 200-step Berka run of test_berka_run_200_steps with the bf16 training GEMMs.  Stated tolerance on the loss curve against
     the fp32 reference curve: the first 10 losses within 5e-3, mean deviation <= 4e-2 and max <= 2e-1 over the 200 steps (measured
