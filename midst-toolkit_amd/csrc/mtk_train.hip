@@ -53,6 +53,8 @@ struct G2 {
     int a16, b16, c16, mask16;
     uint16_t* Ct; int64_t ct_ld;   // optional second copy of the result, transposed and bf16: Ct[n * ct_ld + m]
     int tile64;                    // 64 x 64 tiles whatever the grid size (weight gradients split over the batch: see wgrad_chunk)
+    int dma;                       // the caller vouches for k_gemm2c's conditions (see there): 1 = B has rows up to the next
+                                   // multiple of 64 past N, 2 = of 128
 };
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
@@ -406,11 +408,143 @@ struct TileMoverB<TR, T, true> {
     }
 };
 
+// What follows the k-loop of the bf16 GEMMs (k_gemm2b, k_gemm2c): bias-gradient row sums, then the result tile.  `smem` is the
+// kernel's LDS, free by now (the caller's loop ends with a barrier), at least 4 * 2 * 32 * 40 elements.
+// Wave layout: (waves / 2) x 2, wave (wr, wc) owns MT x NT sub-tiles of 32 x 32 from row 32 MT wr, column 32 NT wc of the tile.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT], float (&rs)[MT], bool sum_rows, uint16_t* smem,
+                                              int64_t m0, int n0, int lane, int wid) {
+    constexpr int CP = 40;  // pitch (elements) of a wave's 32 x 32 staging tiles: 80-byte rows, 16-byte aligned
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    if (sum_rows) {  // lanes l and l + 32 hold the two k-halves of row (lane & 31)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float tot = rs[mt] + __shfl_xor(rs[mt], 32);
+            if (hh == 0) {
+                if (g.rowsum_slab) g.rowsum_slab[(int64_t)blockIdx.z * g.M + m0 + wr * 32 * MT + mt * 32 + li] = tot;
+                else unsafeAtomicAdd(&g.rowsum[m0 + wr * 32 * MT + mt * 32 + li], tot);
+            }
+        }
+    }
+    // bf16 results (activations, activation gradients) leave through LDS: the MFMA layout gives a lane ONE column of the tile, so
+    // storing from it is a 2-byte store per element in 64-byte runs, the ReLU mask is read the same way, and the transposed copy
+    // goes out in 8-byte pieces a row apart (+3 us per copy, +5 us for the mask on a 2,048 x 1,024 result).  Each wave stages its
+    // own 32 x 32 sub-tiles (no workgroup barrier): mask tile in by 16-byte loads, results written over it in place (every
+    // element belongs to one lane) and, transposed, beside it; both leave as 16-byte stores.
+    if (g.c16 && g.c_cs == 1 && (!g.mask || (g.mask16 && g.neg_slope == 0.0f))) {
+        uint16_t* const cs = smem + wid * (2 * 32 * CP);
+        uint16_t* const cst = cs + 32 * CP;
+        uint16_t* const C16 = reinterpret_cast<uint16_t*>(g.C);
+        const uint16_t* const M16 = reinterpret_cast<const uint16_t*>(g.mask);
+        const int prow = lane >> 2, pch = (lane & 3) * 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nb = n0 + wc * 32 * NT + nt * 32;  // wave-uniform (N is a multiple of 32 for these results)
+                if (nb >= g.N) continue;
+                const int64_t rb = m0 + wr * 32 * MT + mt * 32;
+                if (M16) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        *reinterpret_cast<uint4*>(&cs[(prow + 16 * i) * CP + pch]) =
+                            *reinterpret_cast<const uint4*>(M16 + (rb + prow + 16 * i) * g.m_rs + nb + pch);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+                const int n = nb + li;
+                const float bias = g.bias ? g.bias[n] : 0.0f;
+                unsigned tq[8];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int64_t row = rb + lr;
+                    float v = acc[mt][nt][r] + bias;
+                    if (g.emb) {
+                        const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
+                        v += g.emb[(int64_t)tr * g.emb_ld + n];
+                    }
+                    if (g.addend) v += g.addend[row * g.add_rs + n];
+                    if (g.relu == 2) v = v / (1.0f + expf(-v));
+                    else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                    if (M16) {
+                        const unsigned mbits = cs[lr * CP + li];
+                        v = (mbits != 0 && !(mbits & 0x8000u)) ? v : 0.0f;  // > 0 for a bf16 that is not a NaN (activations are not)
+                    }
+                    const __bf16 e = (__bf16)v;
+                    const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
+                    cs[lr * CP + li] = (uint16_t)bits;
+                    if (r & 1) tq[r >> 1] |= bits << 16; else tq[r >> 1] = bits;
+                }
+                if (g.Ct) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(&cst[li * CP + 8 * q + 4 * hh]) = make_uint2(tq[2 * q], tq[2 * q + 1]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pr = prow + 16 * i;
+                    *reinterpret_cast<uint4*>(C16 + (rb + pr) * g.c_rs + nb + pch) = *reinterpret_cast<const uint4*>(&cs[pr * CP + pch]);
+                    if (g.Ct) *reinterpret_cast<uint4*>(g.Ct + (int64_t)(nb + pr) * g.ct_ld + rb + pch) = *reinterpret_cast<const uint4*>(&cst[pr * CP + pch]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        return;
+    }
+    // epilogue: as k_gemm2 (C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
+    // c16: the result is an activation (or an activation gradient) stored as bf16; mask16: the saved activation is
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wc * 32 * NT + nt * 32 + li;
+            if (n >= g.N) continue;
+            const float bias = g.bias ? g.bias[n] : 0.0f;
+            unsigned tq[8];  // the 16 results as bf16 pairs, for the transposed copy
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wr * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[mt][nt][r] + bias;
+                if (g.emb) {
+                    const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
+                    v += g.emb[(int64_t)tr * g.emb_ld + n];
+                }
+                if (g.addend) v += g.addend[row * g.add_rs + n];
+                if (g.relu == 2) v = v / (1.0f + expf(-v));
+                else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                if (g.mask) {
+                    bool pos;
+                    if (g.mask16) {
+                        const uint16_t mbits = reinterpret_cast<const uint16_t*>(g.mask)[row * g.m_rs + n];
+                        pos = mbits != 0 && !(mbits & 0x8000u);  // > 0 for a bf16 that is not a NaN (activations are not)
+                    } else {
+                        pos = g.mask[row * g.m_rs + n] > 0.0f;
+                    }
+                    v = pos ? v : g.neg_slope * v;
+                }
+                if (g.c16) {
+                    const __bf16 e = (__bf16)v;
+                    const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
+                    reinterpret_cast<uint16_t*>(g.C)[row * g.c_rs + (int64_t)n * g.c_cs] = (uint16_t)bits;
+                    if (r & 1) tq[r >> 1] |= bits << 16; else tq[r >> 1] = bits;
+                } else {
+                    float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
+                    if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
+                }
+            }
+            if (g.c16 && g.Ct) {  // registers 4 q .. 4 q + 3 are rows 8 q + 4 hh .. + 3: eight contiguous bytes of column n of C^T
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = m0 + wr * 32 * MT + mt * 32 + 8 * q + 4 * hh;
+                    *reinterpret_cast<uint2*>(&g.Ct[(int64_t)n * g.ct_ld + row]) = make_uint2(tq[2 * q], tq[2 * q + 1]);
+                }
+            }
+        }
+}
+
 template <bool AT, bool BT, int WT, bool A16, bool B16>
 __global__ __launch_bounds__(256) void k_gemm2b(G2 g) {
     constexpr int T = 64 * WT;
-    constexpr int CP = 40;  // pitch (elements) of a wave's 32 x 32 staging tiles in the epilogue: 80-byte rows, 16-byte aligned
-    constexpr int kSmem = 2 * T * PITCH2 > 4 * 2 * 32 * CP ? 2 * T * PITCH2 : 4 * 2 * 32 * CP;
+    constexpr int kSmem = 2 * T * PITCH2 > 4 * 2 * 32 * 40 ? 2 * T * PITCH2 : 4 * 2 * 32 * 40;  // the epilogue stages 32 x 32 tiles here
     __shared__ __attribute__((aligned(16))) uint16_t smem[kSmem];
     uint16_t* const As = smem;
     uint16_t* const Bs = smem + T * PITCH2;
@@ -468,129 +602,133 @@ __global__ __launch_bounds__(256) void k_gemm2b(G2 g) {
         }
         __syncthreads();
     }
-    if (sum_rows) {  // lanes l and l + 32 hold the two k-halves of row (lane & 31)
+    gemm2b_finish<WT, WT>(g, acc, rs, sum_rows, smem, m0, n0, lane, wid);
+}
+
+// The GEMM most of a bf16 iteration runs in: both operands bf16, both read along their rows (the transposed copies exist for
+// this), 64 x 64 tiles.  k_gemm2b holds ONE k-step in registers on its way to LDS, and with two workgroups on a CU a k-step then
+// costs a global round trip (14.7 us for 2,048 x 1,024 x 1,024: 35 GB/s per CU from an L2 that holds both operands).  Here the
+// tiles go L2 -> LDS by LDS-DMA into a ring of kRing stages, kRing - 1 k-steps requested ahead of the one being multiplied, no
+// registers involved, one barrier per k-step.  An LDS-DMA instruction writes 64 lanes x 16 bytes linearly (8 tile rows of 128
+// bytes), so the bank swizzle is applied on the global side, as in mtk_mlp_bf16_layered.hip: slot (r, c) of a tile holds piece
+// c ^ ((r >> 1) & 7) of row r, and a fragment read asks for slot kp ^ ((r >> 1) & 7).
+// Host guarantees (launch): A, B bf16 with rows of >= K elements, K and kchunk multiples of 64, M a multiple of 64, B with rows up to
+// the next multiple of 64 past N.
+constexpr int kRing = 4;
+extern __shared__ __attribute__((aligned(16))) uint16_t g2c_smem[];
+
+// Wave layout WR x 2, every wave MT x NT sub-tiles of 32 x 32: <2, 1, 1> = 64 x 64 tiles, 4 waves, 64 KiB of LDS (two workgroups
+// per CU); <4, 1, 2> = 128 x 128 tiles, 8 waves, 128 KiB.  With 64 x 64 tiles a 2,048 x 1,024 x 1,024 product pulls 134 MB out of
+// the L2s and runs at their ~11 TB/s (12 us whatever the latency hiding); 128 x 128 halves the traffic.  Every wave moves two
+// 8-row pieces of each operand per k-step in both shapes.
+template <int WR, int MT, int NT>
+__global__ __launch_bounds__(WR * 128) void k_gemm2c(G2 g) {
+    constexpr int TM_ = WR * 32 * MT, TN_ = 2 * 32 * NT, NW = WR * 2;
+    constexpr int PA = TM_ / 8 / NW, PB = TN_ / 8 / NW;  // 8-row pieces per wave and k-step
+    static_assert(PA == 2 && PB == 2, "the swizzle key below is written for two pieces per wave");
+    constexpr int kOpA = TM_ * 128, kStage = (TM_ + TN_) * 128;  // bytes: the A tile, one ring stage (A tile | B tile)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * TM_;
+    const int n0 = blockIdx.y * TN_;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    const int nk = (kend - kbeg) / 64;
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-        for (int mt = 0; mt < WT; ++mt) {
-            const float tot = rs[mt] + __shfl_xor(rs[mt], 32);
-            if (hh == 0) {
-                if (g.rowsum_slab) g.rowsum_slab[(int64_t)blockIdx.z * g.M + m0 + wr * 32 * WT + mt * 32 + li] = tot;
-                else unsafeAtomicAdd(&g.rowsum[m0 + wr * 32 * WT + mt * 32 + li], tot);
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const bool sum_rows = (g.rowsum != nullptr || g.rowsum_slab != nullptr) && blockIdx.y == 0 && wc == 0;  // wave-uniform
+    float rs[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) rs[a] = 0.0f;
+
+    // wave wv moves rows [16 wv, 16 wv + 16) of both tiles
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    const int lr = lane >> 3;
+    unsigned voff_a[2], voff_b[2];  // [piece]: row in tile = 16 wv + 8 j + lr, its key (row >> 1) & 7 = (4 j + (lr >> 1)) & 7
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lc = (lane & 7) ^ ((4 * j + (lr >> 1)) & 7);
+        voff_a[j] = (unsigned)(lr * g.lda * 2 + lc * 16);
+        voff_b[j] = (unsigned)(lr * g.ldb * 2 + lc * 16);
+    }
+    const unsigned char* a_base = reinterpret_cast<const unsigned char*>(g.A) + ((m0 + 16 * wv) * g.lda + kbeg) * 2;
+    const unsigned char* b_base = reinterpret_cast<const unsigned char*>(g.B) + (((int64_t)n0 + 16 * wv) * g.ldb + kbeg) * 2;
+    auto issue = [&](int i) {  // k-step i into stage i % kRing
+        const unsigned dst = (unsigned)((i % kRing) * kStage + wv * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned char* ga = a_base + (int64_t)j * 8 * g.lda * 2 + (int64_t)i * 128;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_a[j]), "s"(ga), "s"(dst + j * 1024u) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned char* gb = b_base + (int64_t)j * 8 * g.ldb * 2 + (int64_t)i * 128;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_b[j]), "s"(gb), "s"(dst + (unsigned)kOpA + j * 1024u) : "memory");
+        }
+    };
+    for (int i = 0; i < kRing - 1 && i < nk; ++i) issue(i);
+    const unsigned char* lds = reinterpret_cast<const unsigned char*>(g2c_smem);
+    for (int i = 0; i < nk; ++i) {
+        // k-step i has landed when at most the requests made after it are outstanding: min(kRing - 2, nk - 1 - i) steps of 4
+        const int after = nk - 1 - i;
+        if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's pieces of step i are in LDS, and every wave is done reading step i - 1's stage
+        if (i + kRing - 1 < nk) issue(i + kRing - 1);
+        const unsigned char* st = lds + (i % kRing) * kStage;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kp = 2 * s + hh;
+            bf16x8_t a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ra = wr * 32 * MT + mt * 32 + li;
+                a[mt] = *reinterpret_cast<const bf16x8_t*>(st + ra * 128 + ((kp ^ ((ra >> 1) & 7)) * 16));
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int rb = wc * 32 * NT + nt * 32 + li;
+                b[nt] = *reinterpret_cast<const bf16x8_t*>(st + kOpA + rb * 128 + ((kp ^ ((rb >> 1) & 7)) * 16));
+            }
+            if (sum_rows) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) { t0 += (float)a[mt][j]; t1 += (float)a[mt][j + 1]; }
+                    rs[mt] += t0 + t1;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
     }
-    // bf16 results (activations, activation gradients) leave through LDS: the MFMA layout gives a lane ONE column of the tile, so
-    // storing from it is a 2-byte store per element in 64-byte runs, the ReLU mask is read the same way, and the transposed copy
-    // goes out in 8-byte pieces a row apart (+3 us per copy, +5 us for the mask on a 2,048 x 1,024 result).  Each wave stages its
-    // own 32 x 32 sub-tiles (no workgroup barrier): mask tile in by 16-byte loads, results written over it in place (every
-    // element belongs to one lane) and, transposed, beside it; both leave as 16-byte stores.
-    if (g.c16 && g.c_cs == 1 && (!g.mask || (g.mask16 && g.neg_slope == 0.0f))) {
-        uint16_t* const cs = smem + wid * (2 * 32 * CP);
-        uint16_t* const cst = cs + 32 * CP;
-        uint16_t* const C16 = reinterpret_cast<uint16_t*>(g.C);
-        const uint16_t* const M16 = reinterpret_cast<const uint16_t*>(g.mask);
-        const int prow = lane >> 2, pch = (lane & 3) * 8;
-#pragma unroll
-        for (int mt = 0; mt < WT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < WT; ++nt) {
-                const int nb = n0 + wc * 32 * WT + nt * 32;  // wave-uniform (N is a multiple of 32 for these results)
-                if (nb >= g.N) continue;
-                const int64_t rb = m0 + wr * 32 * WT + mt * 32;
-                if (M16) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        *reinterpret_cast<uint4*>(&cs[(prow + 16 * i) * CP + pch]) =
-                            *reinterpret_cast<const uint4*>(M16 + (rb + prow + 16 * i) * g.m_rs + nb + pch);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                }
-                const int n = nb + li;
-                const float bias = g.bias ? g.bias[n] : 0.0f;
-                unsigned tq[8];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    const int64_t row = rb + lr;
-                    float v = acc[mt][nt][r] + bias;
-                    if (g.emb) {
-                        const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
-                        v += g.emb[(int64_t)tr * g.emb_ld + n];
-                    }
-                    if (g.addend) v += g.addend[row * g.add_rs + n];
-                    if (g.relu == 2) v = v / (1.0f + expf(-v));
-                    else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
-                    if (M16) {
-                        const unsigned mbits = cs[lr * CP + li];
-                        v = (mbits != 0 && !(mbits & 0x8000u)) ? v : 0.0f;  // > 0 for a bf16 that is not a NaN (activations are not)
-                    }
-                    const __bf16 e = (__bf16)v;
-                    const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
-                    cs[lr * CP + li] = (uint16_t)bits;
-                    if (r & 1) tq[r >> 1] |= bits << 16; else tq[r >> 1] = bits;
-                }
-                if (g.Ct) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(&cst[li * CP + 8 * q + 4 * hh]) = make_uint2(tq[2 * q], tq[2 * q + 1]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pr = prow + 16 * i;
-                    *reinterpret_cast<uint4*>(C16 + (rb + pr) * g.c_rs + nb + pch) = *reinterpret_cast<const uint4*>(&cs[pr * CP + pch]);
-                    if (g.Ct) *reinterpret_cast<uint4*>(g.Ct + (int64_t)(nb + pr) * g.ct_ld + rb + pch) = *reinterpret_cast<const uint4*>(&cst[pr * CP + pch]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            }
-        return;
+    __syncthreads();  // the ring is free: the epilogue stages its tiles in it
+    gemm2b_finish<MT, NT>(g, acc, rs, sum_rows, g2c_smem, m0, n0, lane, wid);
+}
+
+template <int WR, int MT, int NT>
+int launch_c(const G2& g, dim3 grid, hipStream_t s) {
+    constexpr int kBytes = kRing * (WR * 32 * MT + 64 * NT) * 128;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    MTK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        MTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2c<WR, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    // epilogue: as k_gemm2 (C/D map of the 32x32 MFMA: column (n) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5));
-    // c16: the result is an activation (or an activation gradient) stored as bf16; mask16: the saved activation is
-#pragma unroll
-    for (int mt = 0; mt < WT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < WT; ++nt) {
-            const int n = n0 + wc * 32 * WT + nt * 32 + li;
-            if (n >= g.N) continue;
-            const float bias = g.bias ? g.bias[n] : 0.0f;
-            unsigned tq[8];  // the 16 results as bf16 pairs, for the transposed copy
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wr * 32 * WT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = acc[mt][nt][r] + bias;
-                if (g.emb) {
-                    const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
-                    v += g.emb[(int64_t)tr * g.emb_ld + n];
-                }
-                if (g.addend) v += g.addend[row * g.add_rs + n];
-                if (g.relu == 2) v = v / (1.0f + expf(-v));
-                else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
-                if (g.mask) {
-                    bool pos;
-                    if (g.mask16) {
-                        const uint16_t mbits = reinterpret_cast<const uint16_t*>(g.mask)[row * g.m_rs + n];
-                        pos = mbits != 0 && !(mbits & 0x8000u);  // > 0 for a bf16 that is not a NaN (activations are not)
-                    } else {
-                        pos = g.mask[row * g.m_rs + n] > 0.0f;
-                    }
-                    v = pos ? v : g.neg_slope * v;
-                }
-                if (g.c16) {
-                    const __bf16 e = (__bf16)v;
-                    const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
-                    reinterpret_cast<uint16_t*>(g.C)[row * g.c_rs + (int64_t)n * g.c_cs] = (uint16_t)bits;
-                    if (r & 1) tq[r >> 1] |= bits << 16; else tq[r >> 1] = bits;
-                } else {
-                    float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
-                    if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
-                }
-            }
-            if (g.c16 && g.Ct) {  // registers 4 q .. 4 q + 3 are rows 8 q + 4 hh .. + 3: eight contiguous bytes of column n of C^T
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t row = m0 + wr * 32 * WT + mt * 32 + 8 * q + 4 * hh;
-                    *reinterpret_cast<uint2*>(&g.Ct[(int64_t)n * g.ct_ld + row]) = make_uint2(tq[2 * q], tq[2 * q + 1]);
-                }
-            }
-        }
+    hipLaunchKernelGGL((k_gemm2c<WR, MT, NT>), grid, dim3(WR * 128), kBytes, s, g);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
 }
 
 template <bool AT, bool BT, int WT>
@@ -607,6 +745,15 @@ int launch(const G2& g, hipStream_t s) {
     const int64_t wg128 = (int64_t)(g.M / TM) * ((g.N + TN - 1) / TN) * splits;
     const dim3 g128((unsigned)(g.M / 128), (unsigned)((g.N + 127) / 128), (unsigned)splits), g64((unsigned)(g.M / 64), (unsigned)((g.N + 63) / 64), (unsigned)splits);
     static const bool old_bf = getenv("MTK_TRAIN_BF16_OLD") != nullptr;  // A/B: the round-2 bf16 instantiation (fp32 tiles in LDS)
+    static const bool no_dma = getenv("MTK_TRAIN_NO_DMA") != nullptr;    // A/B: k_gemm2b where k_gemm2c would run
+    if (g.bf16 && !old_bf && !no_dma && g.dma && !AT && !BT && g.a16 && g.b16 && g.K % 64 == 0 && (g.kchunk % 64 == 0 || g.kchunk == g.K)) {
+        static const int force_wt = getenv("MTK_TRAIN_DMA_WT") ? atoi(getenv("MTK_TRAIN_DMA_WT")) : 0;  // A/B
+        // measured (2,048 and 8,192 rows x 1,024 x 1,024): the 128 x 128 shape is no faster in the loop and slower at 128 workgroups
+        const bool big = force_wt == 2;
+        // a 128-wide B tile reads rows up to the next multiple of 128 past N: the caller's `dma` covers multiples of 64 only
+        if (big && (g.N % 128 == 0 || g.dma == 2)) return launch_c<4, 1, 2>(g, g128, s);
+        return launch_c<2, 1, 1>(g, g64, s);
+    }
     if (wg128 >= 512 && !g.tile64) {
         if (g.bf16 && !old_bf) launch_b<AT, BT, 2>(g, g128, s);
         else if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 2, true>), g128, dim3(256), 0, s, g);
@@ -1105,6 +1252,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         const int t128 = (g.M / TM) * ((g.N + TN - 1) / TN), t64 = (g.M / 64) * ((g.N + 63) / 64);
         g.tile64 = st16 ? 1 : 0;
         g.kchunk = kchunk_for(g.K, st16 ? t64 : t128);
+        if (st16 && g.kchunk < g.K) g.kchunk = (g.kchunk + 63) / 64 * 64;  // k_gemm2c walks 64 rows of the batch per k-step
     };
     if (do_fwd) {
     tr.fwd_rows = B;
@@ -1131,7 +1279,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
         g.A = act_of(i); g.a16 = st16; g.lda = l.in_pad; g.B = w_of(l); g.b16 = st16; g.ldb = l.in_pad;
         g.C = const_cast<float*>(act_of(i + 1)); g.c16 = st16; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32; g.relu = 1;
-        if (st16) { g.Ct = tr.act16t[i + 1]; g.ct_ld = Mpad; }
+        if (st16) { g.Ct = tr.act16t[i + 1]; g.ct_ld = Mpad; g.dma = 2; }  // B = W: out_pad rows, a multiple of 128
         if ((rc = launch<false, false>(g, s))) return rc;
     }
     {
@@ -1141,6 +1289,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.M = (int)Mpad; g.N = l.out; g.K = l.in_pad; g.kchunk = g.K;
         g.A = act_of(c->blocks.size()); g.a16 = st16; g.lda = l.in_pad; g.B = w_of(l); g.b16 = st16; g.ldb = l.in_pad;
         g.C = tr.out; g.c_rs = 1; g.c_cs = ld; g.bias = l.b32;
+        g.dma = st16 ? 2 : 0;  // B = W: out_pad rows
         if ((rc = launch<false, false>(g, s))) return rc;
     }
     }
@@ -1242,7 +1391,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.bf16 = tr.bf16;
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
         g.A = dy; g.a16 = st16; g.lda = l.out_pad; g.B = act_of(i); g.b16 = st16; g.ldb = l.in_pad;
-        if (st16) { g.A = f16(tr.dact16t[cur]); g.lda = Mpad; g.B = f16(tr.act16t[i]); g.ldb = Mpad; }
+        if (st16) { g.A = f16(tr.dact16t[cur]); g.lda = Mpad; g.B = f16(tr.act16t[i]); g.ldb = Mpad; g.dma = 2; }  // act16t[i]: a multiple of 128 rows
         g.c_rs = l.in_pad; g.c_cs = 1;
         // db[o] = sum_m dy[m][o] rides along
         if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
@@ -1253,7 +1402,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         d.A = dy; d.a16 = st16; d.lda = l.out_pad; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
         d.C = const_cast<float*>(dact_of(cur ^ 1)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
         if (i > 0) { d.mask = act_of(i); d.mask16 = st16; d.m_rs = l.in_pad; }  // act[0] (proj + emb) has no ReLU
-        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[cur ^ 1]; d.ct_ld = Mpad; }
+        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[cur ^ 1]; d.ct_ld = Mpad; d.dma = l.in_pad % 64 == 0; }  // W^T has in_pad rows
         if ((rc = st16 ? launch<false, false>(d, s) : launch<false, true>(d, s))) return rc;
         cur ^= 1;
     }
