@@ -73,8 +73,7 @@ struct TrainState {
     uint16_t* w16t = nullptr;          // [n_img]: layer at w_off as [in_pad][out_pad] (hidden layers and head)
     std::vector<uint16_t*> act16;      // act16[i] ~ act[i], row-major [cap16][out_pad]
     std::vector<uint16_t*> act16t;     // act16t[i] = act16[i]^T, [out_pad][Mpad of the call]
-    uint16_t* dact16[2] = {nullptr, nullptr};
-    uint16_t* dact16t[2] = {nullptr, nullptr};
+    std::vector<uint16_t*> dact16, dact16t;  // ~ dact[i] and its transpose
     int64_t cap16 = 0;
     // time-embedding tables kept for the backward pass, [Tpad][tpad]
     float *sin_tab = nullptr, *z0_tab = nullptr, *e1_tab = nullptr, *demb = nullptr, *dtab = nullptr;
@@ -89,7 +88,13 @@ struct TrainState {
     int32_t* xt_idx = nullptr;     // [C][cap]
     std::vector<float*> act;       // act[0] = proj output, act[i] = block i output, row-major [cap][out_pad]
     float *out = nullptr, *dout = nullptr;  // column-major [Dpad128][cap]
-    float* dact[2] = {nullptr, nullptr};   // row-major [cap][max_pad] gradient ping-pong
+    std::vector<float*> dact;      // dact[i] = d loss / d act[i], row-major [cap][width of act[i]] (one per layer: the weight
+                                   // gradients run after the whole input-gradient chain, see train_phases)
+    // Side stream of the iteration: the time-embedding MLP's backward (six small launches) runs under the weight-gradient GEMMs,
+    // and the table refresh after the optimizer step under the optimizer pass over the big layers.  Forked and joined inside
+    // the call, by events, so the caller's stream sees one ordered piece of work.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // deterministic reductions (default): split-K partial tiles / row sums land in slabs and are added in a fixed order;
     // the time-embedding scatter accumulates in 64-bit fixed point.  false: fp32 hardware atomics (order varies run to run).
     bool deterministic = true;

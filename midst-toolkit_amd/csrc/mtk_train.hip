@@ -878,7 +878,8 @@ struct AdamArgs {
     uint16_t* p16;  // optional bf16 copy of the updated weights (bf16 training mode)
     float *p, *m, *v, *ema;
     const float* g;
-    int64_t n;
+    int64_t n;                  // elements this launch updates: two ranges of the image, [beg0, beg0 + len0) then [beg1, beg1 + n - len0)
+    int64_t beg0, len0, beg1;
     float decay;        // 1 - lr * weight_decay
     float beta1_c;      // 1 - beta1
     float beta2, beta2_c;
@@ -887,7 +888,8 @@ struct AdamArgs {
     float eps, ema_rate, ema_c;
 };
 __global__ __launch_bounds__(256) void k_adamw_ema(AdamArgs a) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < a.n; j += (int64_t)gridDim.x * 256) {
+        const int64_t i = j < a.len0 ? a.beg0 + j : a.beg1 + (j - a.len0);
         const float g = a.g[i];
         float p = a.p[i] * a.decay;
         float m = a.m[i];
@@ -966,7 +968,9 @@ std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
 
 void free_acts(TrainState& tr) {
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(tr.xin); fr(tr.xt_idx); fr(tr.out); fr(tr.dout); fr(tr.dact[0]); fr(tr.dact[1]); fr(tr.slab); fr(tr.slab_rs);
+    fr(tr.xin); fr(tr.xt_idx); fr(tr.out); fr(tr.dout); fr(tr.slab); fr(tr.slab_rs);
+    for (auto& p : tr.dact) fr(p);
+    tr.dact.clear();
     tr.slab_elems = tr.slab_rs_elems = 0;
     for (auto& p : tr.act) fr(p);
     tr.act.clear();
@@ -975,7 +979,10 @@ void free_acts(TrainState& tr) {
     tr.act16.clear();
     for (auto& p : tr.act16t) fr(p);
     tr.act16t.clear();
-    fr(tr.dact16[0]); fr(tr.dact16[1]); fr(tr.dact16t[0]); fr(tr.dact16t[1]);
+    for (auto& p : tr.dact16) fr(p);
+    for (auto& p : tr.dact16t) fr(p);
+    tr.dact16.clear();
+    tr.dact16t.clear();
     tr.cap16 = 0;
 }
 
@@ -1001,10 +1008,13 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * Mpad, s));
     MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * Mpad, s));
     tr.xin_rows = tr.dout_rows = 0;
-    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact[i], sizeof(float) * (size_t)Mpad * maxpad));
     tr.act.assign(1 + c->blocks.size(), nullptr);
-    MTK_HIP(hipMalloc(&tr.act[0], sizeof(float) * (size_t)Mpad * c->proj.out_pad));
-    for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act[1 + i], sizeof(float) * (size_t)Mpad * c->blocks[i].out_pad));
+    tr.dact.assign(1 + c->blocks.size(), nullptr);
+    for (size_t i = 0; i <= c->blocks.size(); ++i) {
+        const size_t w = i == 0 ? c->proj.out_pad : c->blocks[i - 1].out_pad;
+        MTK_HIP(hipMalloc(&tr.act[i], sizeof(float) * (size_t)Mpad * w));
+        MTK_HIP(hipMalloc(&tr.dact[i], sizeof(float) * (size_t)Mpad * w));
+    }
     // split-K slabs of the weight-gradient GEMMs (deterministic reductions): every layer has its own region (splits x
     // layer), so that ONE reduction kernel at the end of the backward pass adds all of them
     size_t need = 0, need_rs = 0;
@@ -1070,20 +1080,15 @@ int ensure_acts16(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     if (Mpad <= tr.cap16) return MTK_OK;
     MTK_HIP(hipStreamSynchronize(s));
     auto fr = [](uint16_t*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    for (auto& p : tr.act16) fr(p);
-    for (auto& p : tr.act16t) fr(p);
-    fr(tr.dact16[0]); fr(tr.dact16[1]); fr(tr.dact16t[0]); fr(tr.dact16t[1]);
+    for (auto* v : {&tr.act16, &tr.act16t, &tr.dact16, &tr.dact16t}) {
+        for (auto& p : *v) fr(p);
+        v->assign(1 + c->blocks.size(), nullptr);
+    }
     ++c->ws_gen;
-    int maxpad = c->proj.out_pad;
-    for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
-    tr.act16.assign(1 + c->blocks.size(), nullptr);
-    MTK_HIP(hipMalloc(&tr.act16[0], sizeof(uint16_t) * (size_t)Mpad * c->proj.out_pad));
-    for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act16[1 + i], sizeof(uint16_t) * (size_t)Mpad * c->blocks[i].out_pad));
-    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact16[i], sizeof(uint16_t) * (size_t)Mpad * maxpad));
-    tr.act16t.assign(1 + c->blocks.size(), nullptr);
-    MTK_HIP(hipMalloc(&tr.act16t[0], sizeof(uint16_t) * (size_t)Mpad * c->proj.out_pad));
-    for (size_t i = 0; i < c->blocks.size(); ++i) MTK_HIP(hipMalloc(&tr.act16t[1 + i], sizeof(uint16_t) * (size_t)Mpad * c->blocks[i].out_pad));
-    for (int i = 0; i < 2; ++i) MTK_HIP(hipMalloc(&tr.dact16t[i], sizeof(uint16_t) * (size_t)Mpad * maxpad));
+    for (size_t i = 0; i <= c->blocks.size(); ++i) {
+        const size_t bytes = sizeof(uint16_t) * (size_t)Mpad * (i == 0 ? c->proj.out_pad : c->blocks[i - 1].out_pad);
+        for (auto* v : {&tr.act16, &tr.act16t, &tr.dact16, &tr.dact16t}) MTK_HIP(hipMalloc(&(*v)[i], bytes));
+    }
     tr.cap16 = Mpad;
     return MTK_OK;
 }
@@ -1130,6 +1135,14 @@ void mtk_free_train(mtk_ctx* c) {
     if (tr.demb_fix) (void)hipFree(tr.demb_fix);
     tr.demb_fix = nullptr;
     free_acts(tr);
+    if (tr.side) {
+        (void)hipStreamSynchronize(tr.side);
+        (void)hipStreamDestroy(tr.side);
+        (void)hipEventDestroy(tr.ev_fork);
+        (void)hipEventDestroy(tr.ev_join);
+        tr.side = nullptr;
+        tr.ev_fork = tr.ev_join = nullptr;
+    }
     if (tr.w16) (void)hipFree(tr.w16);
     if (tr.w16t) (void)hipFree(tr.w16t);
     tr.w16 = nullptr;
@@ -1198,6 +1211,11 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     MTK_HIP(hipMalloc(&tr.dtab, tb));
     MTK_HIP(hipMalloc(&tr.demb_fix, sizeof(long long) * (size_t)tr.Tpad * tp));
     MTK_HIP(hipMemsetAsync(tr.demb_fix, 0, sizeof(long long) * (size_t)tr.Tpad * tp, s));
+    if (!tr.side) {
+        MTK_HIP(hipStreamCreateWithFlags(&tr.side, hipStreamNonBlocking));
+        MTK_HIP(hipEventCreateWithFlags(&tr.ev_fork, hipEventDisableTiming));
+        MTK_HIP(hipEventCreateWithFlags(&tr.ev_join, hipEventDisableTiming));
+    }
     float* d_freq = nullptr;
     MTK_HIP(hipMalloc(&d_freq, sizeof(float) * (c->dim_t / 2)));
     MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (c->dim_t / 2), hipMemcpyHostToDevice, s));
@@ -1243,7 +1261,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     auto f16 = [](const uint16_t* p) { return reinterpret_cast<const float*>(p); };
     auto w_of = [&](const MlpLayer& l) { return st16 ? f16(tr.w16 + (l.w32 - tr.state)) : (const float*)l.w32; };
     auto act_of = [&](size_t i) { return st16 ? f16(tr.act16[i]) : (const float*)tr.act[i]; };
-    auto dact_of = [&](int i) { return st16 ? f16(tr.dact16[i]) : (const float*)tr.dact[i]; };
+    auto dact_of = [&](int i) { return st16 ? f16(tr.dact16[i]) : (const float*)tr.dact[i]; };  // d loss / d act[i]
     auto wt_of = [&](const MlpLayer& l) { return f16(tr.w16t + (l.w32 - tr.state)); };  // st16 only: [in_pad][out_pad]
     // Reduction chunk of a weight-gradient GEMM [M x N] over K rows.  A split costs a partial tile written to the slab and read back
     // by k_reduce_splits, and a 128 x 128 tile with 8 splits of a 2,048-row batch runs 4 k-steps per workgroup: with bf16 operands the
@@ -1361,74 +1379,51 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         MTK_HIP(hipEventRecord(tr.bucket_events[bucket++], s));
         return MTK_OK;
     };
-    {   // head: dW[o][k] = sum_m dout[o][m] act[m][k];  db = row sums;  d act = dout^T W  masked by act > 0
+    // Order: the input-gradient chain first (head, hidden layers last to first: each step needs the one before), every
+    // d loss / d act[i] kept; then the weight gradients, which depend on nothing but those - and, on the side stream under them,
+    // the time-embedding MLP's backward (scatter of d act[0] into the table, three small GEMMs), which used to run after the
+    // last of them with the chip idle around it.
+    const int nb = (int)c->blocks.size();
+    {   // head: d act[nb] = dout^T W, masked by act[nb] > 0
         MlpLayer& l = c->head;
-        TrainLayerRef& r = ref_of(&l);
-        G2 g{};
-        g.bf16 = tr.bf16;
-        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
-        g.A = tr.dout; g.lda = ld; g.B = act_of(c->blocks.size()); g.b16 = st16; g.ldb = l.in_pad;
-        if (st16) { g.B = f16(tr.act16t.back()); g.ldb = Mpad; }
-        g.c_rs = l.in_pad; g.c_cs = 1;
-        // db = row sums of dout [out_pad][Mpad] ride along (rows >= out are zero: the padding of the bias gradient is written too)
-        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<false, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
-        if ((rc = bucket_done())) return rc;
         G2 d{};
         d.bf16 = tr.bf16;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = tr.dout; d.lda = ld; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
-        d.C = const_cast<float*>(dact_of(0)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
-        if (!c->blocks.empty()) { d.mask = act_of(c->blocks.size()); d.mask16 = st16; d.m_rs = l.in_pad; }
-        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[0]; d.ct_ld = Mpad; }
+        d.C = const_cast<float*>(dact_of(nb)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
+        if (nb > 0) { d.mask = act_of(nb); d.mask16 = st16; d.m_rs = l.in_pad; }
+        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[nb]; d.ct_ld = Mpad; }
         if ((rc = st16 ? launch<true, false>(d, s) : launch<true, true>(d, s))) return rc;
     }
-    int cur = 0;
-    for (int i = (int)c->blocks.size() - 1; i >= 0; --i) {
+    for (int i = nb - 1; i >= 0; --i) {  // d act[i] = d act[i + 1] W_i (d act[i + 1] is already masked by layer i's ReLU)
         MlpLayer& l = c->blocks[i];
-        TrainLayerRef& r = ref_of(&l);
-        const float* dy = dact_of(cur);  // [Mpad][out_pad], already masked by this layer's ReLU
-        G2 g{};
-        g.bf16 = tr.bf16;
-        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
-        g.A = dy; g.a16 = st16; g.lda = l.out_pad; g.B = act_of(i); g.b16 = st16; g.ldb = l.in_pad;
-        if (st16) { g.A = f16(tr.dact16t[cur]); g.lda = Mpad; g.B = f16(tr.act16t[i]); g.ldb = Mpad; g.dma = 2; }  // act16t[i]: a multiple of 128 rows
-        g.c_rs = l.in_pad; g.c_cs = 1;
-        // db[o] = sum_m dy[m][o] rides along
-        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
-        if ((rc = bucket_done())) return rc;
         G2 d{};
         d.bf16 = tr.bf16;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
-        d.A = dy; d.a16 = st16; d.lda = l.out_pad; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
-        d.C = const_cast<float*>(dact_of(cur ^ 1)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
+        d.A = dact_of(i + 1); d.a16 = st16; d.lda = l.out_pad; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
+        d.C = const_cast<float*>(dact_of(i)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
         if (i > 0) { d.mask = act_of(i); d.mask16 = st16; d.m_rs = l.in_pad; }  // act[0] (proj + emb) has no ReLU
-        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[cur ^ 1]; d.ct_ld = Mpad; d.dma = l.in_pad % 64 == 0; }  // W^T has in_pad rows
+        if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[i]; d.ct_ld = Mpad; d.dma = l.in_pad % 64 == 0; }  // W^T has in_pad rows
         if ((rc = st16 ? launch<false, false>(d, s) : launch<false, true>(d, s))) return rc;
-        cur ^= 1;
     }
-    {   // proj: dW[o][k] = sum_m dact0[m][o] xin[k][m];  db;  d emb table
-        MlpLayer& l = c->proj;
-        TrainLayerRef& r = ref_of(&l);
-        const float* dy = dact_of(cur);  // [Mpad][proj.out_pad]
-        G2 g{};
-        g.bf16 = tr.bf16;
-        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
-        g.A = dy; g.a16 = st16; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
-        if (st16) { g.A = f16(tr.dact16t[cur]); g.lda = Mpad; }
-        g.c_rs = l.in_pad; g.c_cs = 1;
-        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
-        if ((rc = bucket_done())) return rc;
+    static const bool no_side = getenv("MTK_TRAIN_NO_SIDE") != nullptr;  // A/B: everything on the caller's stream
+    hipStream_t ss = (tr.side && !no_side) ? tr.side : s;
+    if (ss != s) {
+        MTK_HIP(hipEventRecord(tr.ev_fork, s));
+        MTK_HIP(hipStreamWaitEvent(ss, tr.ev_fork, 0));
+    }
+    {   // side stream: d emb table = scatter of d act[0] by timestep, then the time-embedding MLP over the T-row table
+        const float* dy = dact_of(0);  // [Mpad][proj.out_pad]
+        const int64_t dy_ld = c->proj.out_pad;
         if (tr.deterministic) {
             const int64_t ne = (int64_t)tr.Tpad * c->emb_ld;
-            if (st16) hipLaunchKernelGGL(k_scatter_emb_fixed<true>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
-            else hipLaunchKernelGGL(k_scatter_emb_fixed<false>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
-            hipLaunchKernelGGL(k_fixed_to_float, dim3(256), dim3(256), 0, s, tr.demb_fix, tr.demb, ne);
+            if (st16) hipLaunchKernelGGL(k_scatter_emb_fixed<true>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
+            else hipLaunchKernelGGL(k_scatter_emb_fixed<false>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, t, B, c->dim_t, tr.demb_fix, c->emb_ld, c->T);
+            hipLaunchKernelGGL(k_fixed_to_float, dim3(256), dim3(256), 0, ss, tr.demb_fix, tr.demb, ne);
         } else {
-            if (st16) hipLaunchKernelGGL(k_scatter_emb<true>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
-            else hipLaunchKernelGGL(k_scatter_emb<false>, dim3(1024), dim3(64, 4), 0, s, (const void*)dy, (int64_t)l.out_pad, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
+            if (st16) hipLaunchKernelGGL(k_scatter_emb<true>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
+            else hipLaunchKernelGGL(k_scatter_emb<false>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
         }
-    }
-    {   // time-embedding MLP over the T-row table
         const int tp = c->emb_ld;
         MlpLayer &l2 = c->temb2, &l0 = c->temb0;
         TrainLayerRef &r2 = ref_of(&l2), &r0 = ref_of(&l0);
@@ -1437,18 +1432,63 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.M = tp; g.N = tp; g.K = tr.Tpad; g.kchunk = kchunk_for(tr.Tpad, (tp / TM) * (tp / TN));
         g.A = tr.demb; g.lda = tp; g.B = tr.e1_tab; g.ldb = tp; g.c_rs = tp; g.c_cs = 1;
         // the bias gradients (column sums of demb / dtab) ride in the GEMMs as the row sums of their transposed A operand
-        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r2.w_off, grads + r2.b_off))) return rc;
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, ss); }, grads + r2.w_off, grads + r2.b_off))) return rc;
         G2 d{};
         d.bf16 = tr.bf16;
         d.M = tr.Tpad; d.N = tp; d.K = tp; d.kchunk = tp;
         d.A = tr.demb; d.lda = tp; d.B = l2.w32; d.ldb = tp; d.C = tr.dtab; d.c_rs = tp; d.c_cs = 1;
-        if ((rc = launch<false, true>(d, s))) return rc;
-        hipLaunchKernelGGL(k_silu_bwd, dim3(256), dim3(256), 0, s, tr.z0_tab, tr.dtab, (int64_t)tr.Tpad * tp);
+        if ((rc = launch<false, true>(d, ss))) return rc;
+        hipLaunchKernelGGL(k_silu_bwd, dim3(256), dim3(256), 0, ss, tr.z0_tab, tr.dtab, (int64_t)tr.Tpad * tp);
         g.A = tr.dtab; g.B = tr.sin_tab;
         g.slab = nullptr; g.rowsum_slab = nullptr;
-        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, s); }, grads + r0.w_off, grads + r0.b_off))) return rc;
+        if ((rc = wgrad(g, [&](const G2& q) { return launch<true, true>(q, ss); }, grads + r0.w_off, grads + r0.b_off))) return rc;
+        if (ss != s) MTK_HIP(hipEventRecord(tr.ev_join, ss));
     }
-    if (bucketed) {
+    // The time-embedding segments were entered first; the buckets below are cut from the segment list in completion order, so
+    // the main stream's segments start after them and the time-embedding bucket (the last) takes the leading ones.
+    const int temb_segs = segs.n;
+    seg_mark = temb_segs;
+    {   // head: dW[o][k] = sum_m dout[o][m] act[nb][m][k];  db = row sums of dout
+        MlpLayer& l = c->head;
+        TrainLayerRef& r = ref_of(&l);
+        G2 g{};
+        g.bf16 = tr.bf16;
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
+        g.A = tr.dout; g.lda = ld; g.B = act_of(nb); g.b16 = st16; g.ldb = l.in_pad;
+        if (st16) { g.B = f16(tr.act16t[nb]); g.ldb = Mpad; }
+        g.c_rs = l.in_pad; g.c_cs = 1;
+        // db = row sums of dout [out_pad][Mpad] ride along (rows >= out are zero: the padding of the bias gradient is written too)
+        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<false, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = bucket_done())) return rc;
+    }
+    for (int i = nb - 1; i >= 0; --i) {  // dW_i[o][k] = sum_m d act[i + 1][m][o] act[i][m][k];  db[o] = sum_m d act[i + 1][m][o] rides along
+        MlpLayer& l = c->blocks[i];
+        TrainLayerRef& r = ref_of(&l);
+        G2 g{};
+        g.bf16 = tr.bf16;
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
+        g.A = dact_of(i + 1); g.a16 = st16; g.lda = l.out_pad; g.B = act_of(i); g.b16 = st16; g.ldb = l.in_pad;
+        if (st16) { g.A = f16(tr.dact16t[i + 1]); g.lda = Mpad; g.B = f16(tr.act16t[i]); g.ldb = Mpad; g.dma = 2; }  // act16t[i]: a multiple of 128 rows
+        g.c_rs = l.in_pad; g.c_cs = 1;
+        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = bucket_done())) return rc;
+    }
+    {   // proj: dW[o][k] = sum_m d act[0][m][o] xin[k][m];  db
+        MlpLayer& l = c->proj;
+        TrainLayerRef& r = ref_of(&l);
+        G2 g{};
+        g.bf16 = tr.bf16;
+        g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
+        g.A = dact_of(0); g.a16 = st16; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
+        if (st16) { g.A = f16(tr.dact16t[0]); g.lda = Mpad; }
+        g.c_rs = l.in_pad; g.c_cs = 1;
+        if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
+        if ((rc = bucket_done())) return rc;
+    }
+    if (ss != s) MTK_HIP(hipStreamWaitEvent(s, tr.ev_join, 0));
+    if (bucketed) {  // the last bucket: the time-embedding MLP's segments, entered first
+        seg_mark = 0;
+        segs.n = temb_segs;
         if ((rc = bucket_done())) return rc;
     } else if (segs.n > 0) {  // every split-batch partial of the iteration, added in slice order by one launch
         hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)segs.n), dim3(256), 0, s, segs);
@@ -1544,7 +1584,6 @@ extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, doubl
     AdamArgs a;
     a.p16 = tr.w16;
     a.p = tr.state; a.g = tr.state + n; a.m = tr.state + 2 * n; a.v = tr.state + 3 * n; a.ema = tr.state + 4 * n;
-    a.n = (int64_t)n;
     a.decay = (float)(1.0 - lr * weight_decay);
     a.beta1_c = (float)(1.0 - beta1);
     a.beta2 = (float)beta2;
@@ -1554,11 +1593,27 @@ extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, doubl
     a.eps = (float)eps;
     a.ema_rate = (float)ema_rate;
     a.ema_c = (float)(1.0 - ema_rate);
+    // The image is [proj | temb0 | temb2 | hidden layers | head] (layer_list).  The time-embedding MLP's two small layers are updated
+    // first, on the side stream, followed there by the rebuild of the [T, dim_t] table from them (three small launches); the
+    // pass over everything else and the bf16 transposes run beside them on the caller's stream.
+    static const bool no_side = getenv("MTK_TRAIN_NO_SIDE") != nullptr;
+    hipStream_t ss = (tr.side && !no_side) ? tr.side : s;
+    const int64_t t_beg = (int64_t)tr.layers[1].w_off, t_end = (int64_t)tr.layers[3].w_off;
+    if (ss != s) {
+        MTK_HIP(hipEventRecord(tr.ev_fork, s));
+        MTK_HIP(hipStreamWaitEvent(ss, tr.ev_fork, 0));
+    }
+    a.beg0 = t_beg; a.len0 = t_end - t_beg; a.beg1 = 0; a.n = a.len0;
+    hipLaunchKernelGGL(k_adamw_ema, dim3(64), dim3(256), 0, ss, a);
+    int rc = refresh_emb(c, ss);
+    if (rc) return rc;
+    if (ss != s) MTK_HIP(hipEventRecord(tr.ev_join, ss));
+    a.beg0 = 0; a.len0 = t_beg; a.beg1 = t_end; a.n = (int64_t)n - (t_end - t_beg);
     hipLaunchKernelGGL(k_adamw_ema, dim3(1024), dim3(256), 0, s, a);
     MTK_HIP(hipGetLastError());
-    const int rc = refresh_w16t(c, s);
-    if (rc) return rc;
-    return refresh_emb(c, s);
+    if ((rc = refresh_w16t(c, s))) return rc;
+    if (ss != s) MTK_HIP(hipStreamWaitEvent(s, tr.ev_join, 0));
+    return MTK_OK;
 }
 
 extern "C" int mtk_train_export(mtk_ctx* c, int image, float* const* W, float* const* b, mtk_stream stream) {

@@ -107,8 +107,10 @@ class ClavaDDPMTrainer:
         t = t.to(x0.device, torch.int64).contiguous()
         eps = eps.float().contiguous() if eps is not None and eps.numel() else None
         u = u.float().contiguous() if u is not None and u.numel() else None
-        lm = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None
-        lg = torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None
+        # both per-row loss vectors in one buffer: their batch means are one reduction launch, not two plus a fill for the absent one
+        rows = torch.empty((2, B), dtype=torch.float32, device=x0.device) if (eng.C > 0 and eng.Nn > 0) else None
+        lm = rows[0] if rows is not None else (torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None)
+        lg = rows[1] if rows is not None else (torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None)
         eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
         if self._exchange is not None:  # the one exchange of an iteration, bucket by bucket under the backward
             self._exchange.launch()
@@ -116,6 +118,9 @@ class ClavaDDPMTrainer:
         g = self.optimizer.param_groups[0]
         self.optimizer.steps_done += 1
         eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
+        if rows is not None:
+            means = rows.mean(dim=1)
+            return means[0], means[1]
         zero = torch.zeros((), dtype=torch.float32, device=x0.device)
         return (lm.mean() if lm is not None else zero), (lg.mean() if lg is not None else zero)
 
