@@ -112,6 +112,11 @@ int mtk_ctx_set_seed_source(mtk_ctx* ctx, const uint64_t* seed_row0_dev);
  * mtk_mlp_set_weights.  A HIP graph captured from this context's entry points holds raw addresses of those buffers: its owner
  * records the value at capture time and re-captures (never replays) once it differs.  -1 for a null context. */
 int64_t mtk_ctx_workspace_generation(mtk_ctx* ctx);
+/* No reference counterpart: how many hipMalloc calls the context's weight path (mtk_mlp_set_weights and the image packers it
+ * runs) has made so far.  A second mtk_mlp_set_weights with unchanged layer shapes rewrites the images in place - it takes
+ * its blocks back from the context's pool, allocates nothing, frees nothing and does not synchronise the stream - so the
+ * count does not move across it (tests/test_gpu_parity.py checks exactly that).  -1 for a null context. */
+int64_t mtk_ctx_alloc_count(mtk_ctx* ctx);
 
 /* MODEL:583-585, 610-612 (IsTargetConditioned.EMBEDDING with num_classes > 0): the denoiser adds
  * silu(label_embedding.weight[y]) to the time embedding of every record.  Here a (label, timestep) pair is ONE row of the

@@ -37,6 +37,7 @@ _SIGS = {
     "mtk_ctx_reserve": (C.c_int, [_p, _i64, _p]),
     "mtk_ctx_set_seed_source": (C.c_int, [_p, _p]),
     "mtk_ctx_workspace_generation": (_i64, [_p]),
+    "mtk_ctx_alloc_count": (_i64, [_p]),
     "mtk_mlp_set_weights": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p]),
     "mtk_mlp_set_label_embedding": (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),
     "mtk_mlp_forward": (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i32, _p, _i64, _i64, _i32, _p]),

@@ -16,7 +16,7 @@ void mtk_set_error(const char* fmt, ...) {
 extern "C" const char* mtk_last_error(void) { return g_err; }
 extern "C" int mtk_version(void) { return 100; }
 
-void mtk_free_mlp(mtk_ctx* c);  // mtk_mlp_f32.hip
+void mtk_free_mlp(mtk_ctx* c, bool keep_ws);  // mtk_mlp_f32.hip
 int mtk_noalloc_init(int device);  // mtk_mlp_f32.hip: resolves this device's copy of the static scratch array
 
 extern "C" int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K_host, const float* logK_host,
@@ -84,10 +84,55 @@ extern "C" int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K
 
 extern "C" int64_t mtk_ctx_workspace_generation(mtk_ctx* c) { return c ? (int64_t)c->ws_gen : -1; }
 
+extern "C" int64_t mtk_ctx_alloc_count(mtk_ctx* c) { return c ? (int64_t)c->n_malloc : -1; }
+
+int mtk_alloc(mtk_ctx* c, void** p, size_t bytes) {
+    for (size_t i = 0; i < c->pool.size(); ++i) {
+        if (c->pool[i].bytes != bytes) continue;
+        *p = c->pool[i].p;
+        c->pool.erase(c->pool.begin() + (long)i);
+        c->alloc_bytes[*p] = bytes;
+        return MTK_OK;
+    }
+    *p = nullptr;
+    MTK_HIP(hipMalloc(p, bytes));
+    ++c->n_malloc;
+    c->alloc_bytes[*p] = bytes;
+    return MTK_OK;
+}
+
+void mtk_release(mtk_ctx* c, void* p) {
+    if (!p) return;
+    auto it = c->alloc_bytes.find(p);
+    if (it != c->alloc_bytes.end() && c->pooling) {
+        c->pool.push_back({p, it->second, c->pool_gen});
+        c->alloc_bytes.erase(it);
+        return;
+    }
+    if (it != c->alloc_bytes.end()) c->alloc_bytes.erase(it);
+    (void)hipFree(p);
+}
+
+bool mtk_pool_has_stale(const mtk_ctx* c, uint64_t min_gen) {
+    for (auto& b : c->pool) if (b.gen < min_gen) return true;
+    return false;
+}
+
+void mtk_pool_drain(mtk_ctx* c, uint64_t min_gen) {
+    size_t keep = 0;
+    for (auto& b : c->pool) {
+        if (b.gen < min_gen) (void)hipFree(b.p);
+        else c->pool[keep++] = b;
+    }
+    c->pool.resize(keep);
+}
+
 extern "C" void mtk_ctx_destroy(mtk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    mtk_free_mlp(c);
+    c->pooling = false;
+    mtk_free_mlp(c, false);
+    mtk_pool_drain(c, UINT64_MAX);
     if (c->d_rows) (void)hipFree(c->d_rows);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_logK) (void)hipFree(c->d_logK);

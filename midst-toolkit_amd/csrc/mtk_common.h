@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "mtk.h"
@@ -122,6 +123,17 @@ struct mtk_ctx {
     // growing, the packed weight images being rebuilt.  A captured HIP graph holds raw addresses of those buffers; its owner
     // compares mtk_ctx_workspace_generation() with the value at capture time and re-captures when it moved.
     uint64_t ws_gen = 0;
+    // Recycling of the weight images (mtk_alloc / mtk_release below).  mtk_mlp_set_weights releases the old images into `pool`
+    // instead of hipFree'ing them and takes blocks of the same size back out: with unchanged layer shapes it performs no
+    // hipMalloc, no hipFree and no stream synchronisation (hipFree is a device-wide one), and the rewrite is ordered on the
+    // caller's stream like any other work.  A block that sat in the pool through a whole mtk_mlp_set_weights call unclaimed
+    // (the shapes changed) is freed at the start of the next one.
+    struct PoolBlock { void* p; size_t bytes; uint64_t gen; };
+    std::vector<PoolBlock> pool;
+    std::unordered_map<void*, size_t> alloc_bytes;  // blocks handed out by mtk_alloc
+    uint64_t pool_gen = 0;
+    uint64_t n_malloc = 0;  // hipMalloc calls made by mtk_alloc (mtk_ctx_alloc_count)
+    bool pooling = false;  // mtk_release keeps blocks (inside mtk_mlp_set_weights) or frees them (everywhere else)
     bool fast_math = false;  // MTK_MATH_FAST: diffusion kernels on hardware transcendentals, exact block LSE
     // denoiser
     bool have_weights = false;
@@ -170,6 +182,14 @@ struct mtk_ctx {
     DevTables dev() const { return DevTables{d_rows, d_off, d_logK, T, Nn, C, S}; }
     double tab(int which, int t) const { return tables[(size_t)which * T + t]; }
 };
+
+// mtk_capi.hip.  mtk_alloc: a block of exactly `bytes` from the context's pool, else hipMalloc.  mtk_release: back to the pool while
+// `pooling`, else hipFree (null is ignored).  mtk_pool_drain: hipFree the pool's blocks older than `min_gen` (all: UINT64_MAX).
+int mtk_alloc(mtk_ctx* c, void** p, size_t bytes);
+void mtk_release(mtk_ctx* c, void* p);
+bool mtk_pool_has_stale(const mtk_ctx* c, uint64_t min_gen);
+void mtk_pool_drain(mtk_ctx* c, uint64_t min_gen);
+template <typename T> inline int mtk_alloc_t(mtk_ctx* c, T** p, size_t bytes) { return mtk_alloc(c, reinterpret_cast<void**>(p), bytes); }
 
 // ----------------------------------------------------------------------------- device helpers
 #define MTK_LOG_TINY (-0x1.144f6ap+6f) /* fp32 log(1e-30f) = -69.07755, DU:227 */

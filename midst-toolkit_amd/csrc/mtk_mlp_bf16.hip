@@ -817,18 +817,20 @@ __global__ void k_compact_rows(float* dst, int ld, const float* src, int64_t src
 
 }  // namespace
 
-void mtk_free_fused(mtk_ctx* c) {
-    if (c->d_wfrag) (void)hipFree(c->d_wfrag);
-    if (c->d_bias_all) (void)hipFree(c->d_bias_all);
-    if (c->d_embb) (void)hipFree(c->d_embb);
-    if (c->d_wfrag_tf) (void)hipFree(c->d_wfrag_tf);
-    if (c->d_embf) (void)hipFree(c->d_embf);
+void mtk_free_fused(mtk_ctx* c, bool keep_ws) {
+    mtk_release(c, c->d_wfrag);
+    mtk_release(c, c->d_bias_all);
+    mtk_release(c, c->d_embb);
+    mtk_release(c, c->d_wfrag_tf);
+    mtk_release(c, c->d_embf);
     c->d_wfrag_tf = nullptr;
     c->d_embf = nullptr;
     c->tf_chunks = 0;
-    if (c->tf_pack) (void)hipFree(c->tf_pack);
-    c->tf_pack = nullptr;
-    c->tf_pack_elems = 0;
+    if (!keep_ws) {  // the compact record copy of the Tartan-Federer path is scratch, not part of the weight image
+        if (c->tf_pack) (void)hipFree(c->tf_pack);
+        c->tf_pack = nullptr;
+        c->tf_pack_elems = 0;
+    }
     c->d_embb = nullptr;
     c->d_wfrag = nullptr;
     c->d_bias_all = nullptr;
@@ -840,7 +842,8 @@ void mtk_free_fused(mtk_ctx* c) {
 // fragment stream.  Shapes the fused kernel does not cover leave fused_ok = false (MTK_PREC_BF16 then
 // reports MTK_ERR_UNSUPPORTED; MTK_PREC_FP32 always works).
 int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
-    mtk_free_fused(c);
+    mtk_free_fused(c, true);
+    int rc;
     Layout L;
     if (!layout_for(c, L)) return MTK_OK;
     static bool attr_set = false;
@@ -857,9 +860,9 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
         attr_set = true;
     }
     c->wfrag_bytes = (size_t)L.total_chunks * kChunkBytes;
-    MTK_HIP(hipMalloc(&c->d_wfrag, c->wfrag_bytes));
-    MTK_HIP(hipMalloc(&c->d_bias_all, sizeof(float) * L.n_bias));
-    MTK_HIP(hipMalloc(&c->d_embb, sizeof(float) * (size_t)c->T * c->emb_ld));
+    if ((rc = mtk_alloc(c, &c->d_wfrag, c->wfrag_bytes))) return rc;
+    if ((rc = mtk_alloc_t(c, &c->d_bias_all, sizeof(float) * L.n_bias))) return rc;
+    if ((rc = mtk_alloc_t(c, &c->d_embb, sizeof(float) * (size_t)c->T * c->emb_ld))) return rc;
     hipLaunchKernelGGL(k_add_bias_rows, dim3(256), dim3(256), 0, s, c->d_embb, c->d_emb, c->proj.b32, c->T, c->emb_ld, kDimT);
     MTK_HIP(hipMemsetAsync(c->d_wfrag, 0, c->wfrag_bytes, s));
     MTK_HIP(hipMemsetAsync(c->d_bias_all, 0, sizeof(float) * L.n_bias, s));
@@ -885,9 +888,9 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
     {   // the Tartan-Federer stream: the folded D -> H layer, then the hidden layers and the head as they stand above
         const int ldf = 32 * L.DT, c_f = nth * 2 * L.DT / kChunkFrags;
         float* Wf = nullptr;
-        MTK_HIP(hipMalloc(&Wf, sizeof(float) * (size_t)H * ldf));
-        MTK_HIP(hipMalloc(&c->d_wfrag_tf, (size_t)L.tf_chunks * kChunkBytes));
-        MTK_HIP(hipMalloc(&c->d_embf, sizeof(float) * (size_t)c->T * H));
+        if ((rc = mtk_alloc_t(c, &Wf, sizeof(float) * (size_t)H * ldf))) return rc;
+        if ((rc = mtk_alloc(c, &c->d_wfrag_tf, (size_t)L.tf_chunks * kChunkBytes))) return rc;
+        if ((rc = mtk_alloc_t(c, &c->d_embf, sizeof(float) * (size_t)c->T * H))) return rc;
         hipLaunchKernelGGL(k_fold_w, dim3(64), dim3(256), 0, s, Wf, ldf, c->blocks[0].w32, c->blocks[0].in_pad, c->proj.w32, c->proj.in_pad, H, kDimT, c->D);
         hipLaunchKernelGGL(k_fold_emb, dim3(1024), dim3(256), 0, s, c->d_embf, c->blocks[0].w32, c->blocks[0].in_pad, c->d_embb, c->emb_ld,
                            c->blocks[0].b32, c->T, H, kDimT);
@@ -897,12 +900,11 @@ int mtk_pack_fused(mtk_ctx* c, hipStream_t s) {
                                reinterpret_cast<const unsigned char*>(c->d_wfrag) + (size_t)L.tail_chunk0 * kChunkBytes,
                                (size_t)(L.total_chunks - L.tail_chunk0) * kChunkBytes, hipMemcpyDeviceToDevice, s));
         MTK_HIP(hipGetLastError());
-        MTK_HIP(hipStreamSynchronize(s));
-        (void)hipFree(Wf);
+        if (!c->pooling) MTK_HIP(hipStreamSynchronize(s));  // outside mtk_mlp_set_weights the scratch is freed, not pooled
+        mtk_release(c, Wf);
         c->tf_chunks = L.tf_chunks;
     }
     MTK_HIP(hipGetLastError());
-    MTK_HIP(hipStreamSynchronize(s));
     c->fused_ok = true;
     c->fused_h = H;
     return MTK_OK;

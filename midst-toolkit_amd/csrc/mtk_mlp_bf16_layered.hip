@@ -799,30 +799,33 @@ int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
 
 }  // namespace
 
-void mtk_free_layered(mtk_ctx* c) {
-    for (void* p : c->wb16) if (p) (void)hipFree(p);
+void mtk_free_layered(mtk_ctx* c, bool keep_ws) {
+    for (void* p : c->wb16) mtk_release(c, p);
     c->wb16.clear();
-    for (void* p : c->wb16x) if (p) (void)hipFree(p);
+    for (void* p : c->wb16x) mtk_release(c, p);
     c->wb16x.clear();
-    for (float* p : c->bb16) if (p) (void)hipFree(p);
+    for (float* p : c->bb16) mtk_release(c, p);
     c->bb16.clear();
-    if (c->wb16_fold) (void)hipFree(c->wb16_fold);
-    if (c->embf_l) (void)hipFree(c->embf_l);
+    mtk_release(c, c->wb16_fold);
+    mtk_release(c, c->embf_l);
     c->wb16_fold = nullptr;
     c->embf_l = nullptr;
     c->embf_ld = 0;
-    for (int i = 0; i < 2; ++i) {
-        if (c->ws16[i]) (void)hipFree(c->ws16[i]);
-        c->ws16[i] = nullptr;
+    if (!keep_ws) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->ws16[i]) (void)hipFree(c->ws16[i]);
+            c->ws16[i] = nullptr;
+        }
+        c->ws16_elems = 0;
     }
-    c->ws16_elems = 0;
 }
 
 // Weight images for the layer-by-layer bf16 GEMMs, built when the weights are set: fp32 biases padded to
 // round_up(out, 256); split images [round_up(out, 256)][2 round_up(in_pad, 64)] (hi | lo) for MTK_PREC_BF16X3, always; plain
 // bf16 images [round_up(out, 256)][round_up(in_pad, 64)] for MTK_PREC_BF16 when the fused kernel does not cover the shape.
 int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain) {
-    mtk_free_layered(c);
+    mtk_free_layered(c, true);
+    int rc;
     std::vector<const MlpLayer*> ls{&c->proj};
     for (auto& l : c->blocks) ls.push_back(&l);
     ls.push_back(&c->head);
@@ -831,15 +834,15 @@ int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain) {
         void* p = nullptr;
         float* b = nullptr;
         if (plain) {
-            MTK_HIP(hipMalloc(&p, sizeof(uint16_t) * (size_t)np * kp));
+            if ((rc = mtk_alloc(c, &p, sizeof(uint16_t) * (size_t)np * kp))) return rc;
             c->wb16.push_back(p);
             hipLaunchKernelGGL(k_to_bf16_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(p), np, kp, l->w32, l->in_pad, l->out_pad, l->in_pad);
         }
         void* px = nullptr;
-        MTK_HIP(hipMalloc(&px, sizeof(uint16_t) * (size_t)np * kp * 2));
+        if ((rc = mtk_alloc(c, &px, sizeof(uint16_t) * (size_t)np * kp * 2))) return rc;
         c->wb16x.push_back(px);
         hipLaunchKernelGGL(k_to_bf16_split_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(px), np, kp, l->w32, l->in_pad, l->out_pad, l->in_pad);
-        MTK_HIP(hipMalloc(&b, sizeof(float) * (size_t)np));
+        if ((rc = mtk_alloc_t(c, &b, sizeof(float) * (size_t)np))) return rc;
         c->bb16.push_back(b);
         hipLaunchKernelGGL(k_pad_f32, dim3(8), dim3(256), 0, s, b, np, l->b32, l->out_pad);
     }
@@ -847,9 +850,9 @@ int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain) {
         const MlpLayer& l1 = c->blocks[0];
         const int kp0 = round_up(c->proj.in_pad, BK), np1 = round_up(l1.out_pad, BT);
         float* Wf = nullptr;
-        MTK_HIP(hipMalloc(&Wf, sizeof(float) * (size_t)l1.out_pad * c->proj.in_pad));
-        MTK_HIP(hipMalloc(&c->wb16_fold, sizeof(uint16_t) * (size_t)np1 * kp0));
-        MTK_HIP(hipMalloc(&c->embf_l, sizeof(float) * (size_t)c->T * np1));
+        if ((rc = mtk_alloc_t(c, &Wf, sizeof(float) * (size_t)l1.out_pad * c->proj.in_pad))) return rc;
+        if ((rc = mtk_alloc(c, &c->wb16_fold, sizeof(uint16_t) * (size_t)np1 * kp0))) return rc;
+        if ((rc = mtk_alloc_t(c, &c->embf_l, sizeof(float) * (size_t)c->T * np1))) return rc;
         c->embf_ld = np1;
         hipLaunchKernelGGL(k_fold_w_l, dim3(512), dim3(256), 0, s, Wf, c->proj.in_pad, l1.w32, l1.in_pad, c->proj.w32, c->proj.in_pad, l1.out_pad, c->dim_t);
         hipLaunchKernelGGL(k_to_bf16_pad, dim3(512), dim3(256), 0, s, reinterpret_cast<uint16_t*>(c->wb16_fold), np1, kp0, Wf, c->proj.in_pad, l1.out_pad,
@@ -857,8 +860,8 @@ int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain) {
         hipLaunchKernelGGL(k_fold_emb_l, dim3(1024), dim3(256), 0, s, c->embf_l, np1, l1.out, l1.w32, l1.in_pad, c->d_emb, c->emb_ld, c->proj.b32, l1.b32,
                            c->T, c->dim_t);
         MTK_HIP(hipGetLastError());
-        MTK_HIP(hipStreamSynchronize(s));
-        (void)hipFree(Wf);
+        if (!c->pooling) MTK_HIP(hipStreamSynchronize(s));
+        mtk_release(c, Wf);
     }
     MTK_HIP(hipGetLastError());
     return MTK_OK;

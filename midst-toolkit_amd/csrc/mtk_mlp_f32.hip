@@ -9,9 +9,9 @@
 #include "mtk_common.h"
 
 int mtk_pack_fused(mtk_ctx* c, hipStream_t s);    // mtk_mlp_bf16.hip
-void mtk_free_fused(mtk_ctx* c);                  // mtk_mlp_bf16.hip
+void mtk_free_fused(mtk_ctx* c, bool keep_ws);    // mtk_mlp_bf16.hip
 void mtk_free_train(mtk_ctx* c);                  // mtk_train.hip
-void mtk_free_layered(mtk_ctx* c);                // mtk_mlp_bf16_layered.hip
+void mtk_free_layered(mtk_ctx* c, bool keep_ws);  // mtk_mlp_bf16_layered.hip
 int mtk_pack_layered(mtk_ctx* c, hipStream_t s, bool plain);  // mtk_mlp_bf16_layered.hip
 int mtk_layered_bf16_forward(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t x_cs, const int64_t* t, int t_scalar,
                              float* out, int64_t o_rs, int64_t o_cs, hipStream_t s);  // mtk_mlp_bf16_layered.hip
@@ -187,20 +187,23 @@ __global__ void k_add_label_rows(float* emb, int ld, int T, int period, const fl
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-void free_layer(MlpLayer& l) {
-    if (l.owned && l.w32) (void)hipFree(l.w32);
-    if (l.owned && l.b32) (void)hipFree(l.b32);
+void free_layer(mtk_ctx* c, MlpLayer& l) {
+    if (l.owned) {
+        mtk_release(c, l.w32);
+        mtk_release(c, l.b32);
+    }
     l = MlpLayer();
 }
 
-int make_layer(MlpLayer& l, int in, int out, int in_pad, const float* W, const float* b, hipStream_t s) {
-    free_layer(l);
+int make_layer(mtk_ctx* c, MlpLayer& l, int in, int out, int in_pad, const float* W, const float* b, hipStream_t s) {
+    free_layer(c, l);
     l.in = in;
     l.out = out;
     l.in_pad = in_pad;
     l.out_pad = round_up(out, BN);
-    MTK_HIP(hipMalloc(&l.w32, sizeof(float) * (size_t)l.out_pad * l.in_pad));
-    MTK_HIP(hipMalloc(&l.b32, sizeof(float) * (size_t)l.out_pad));
+    int rc;
+    if ((rc = mtk_alloc_t(c, &l.w32, sizeof(float) * (size_t)l.out_pad * l.in_pad))) return rc;
+    if ((rc = mtk_alloc_t(c, &l.b32, sizeof(float) * (size_t)l.out_pad))) return rc;
     hipLaunchKernelGGL(k_pad_copy, dim3(256), dim3(256), 0, s, l.w32, l.out_pad, l.in_pad, W, out, in);
     hipLaunchKernelGGL(k_pad_copy, dim3(4), dim3(256), 0, s, l.b32, 1, l.out_pad, b, 1, out);
     MTK_HIP(hipGetLastError());
@@ -216,31 +219,35 @@ int launch_gemm(const GemmArgs& g, int64_t Mpad, int Npad, hipStream_t s) {
 
 }  // namespace
 
-void mtk_free_mlp(mtk_ctx* c) {
+// keep_ws: the activation workspaces stay (they are scratch sized in elements; the ensure_* functions grow them when a new
+// shape needs more) - what mtk_mlp_set_weights asks for, so that a weight update leaves nothing to reallocate.
+void mtk_free_mlp(mtk_ctx* c, bool keep_ws) {
     ++c->ws_gen;
-    free_layer(c->proj);
-    free_layer(c->temb0);
-    free_layer(c->temb2);
-    free_layer(c->head);
-    for (auto& l : c->blocks) free_layer(l);
+    free_layer(c, c->proj);
+    free_layer(c, c->temb0);
+    free_layer(c, c->temb2);
+    free_layer(c, c->head);
+    for (auto& l : c->blocks) free_layer(c, l);
     c->blocks.clear();
-    if (c->d_emb) (void)hipFree(c->d_emb);
+    mtk_release(c, c->d_emb);
     c->d_emb = nullptr;
-    for (int i = 0; i < 2; ++i) {
-        if (c->ws[i]) (void)hipFree(c->ws[i]);
-        c->ws[i] = nullptr;
+    if (!keep_ws) {
+        for (int i = 0; i < 2; ++i) {
+            if (c->ws[i]) (void)hipFree(c->ws[i]);
+            c->ws[i] = nullptr;
+        }
+        c->ws_elems = 0;
+        for (int i = 0; i < 2; ++i) {
+            if (c->tf_ws[i]) (void)hipFree(c->tf_ws[i]);
+            c->tf_ws[i] = nullptr;
+        }
+        c->tf_ws_elems = 0;
+        if (c->tf_tvec) (void)hipFree(c->tf_tvec);
+        c->tf_tvec = nullptr;
+        c->tf_tvec_elems = 0;
     }
-    c->ws_elems = 0;
-    for (int i = 0; i < 2; ++i) {
-        if (c->tf_ws[i]) (void)hipFree(c->tf_ws[i]);
-        c->tf_ws[i] = nullptr;
-    }
-    c->tf_ws_elems = 0;
-    if (c->tf_tvec) (void)hipFree(c->tf_tvec);
-    c->tf_tvec = nullptr;
-    c->tf_tvec_elems = 0;
-    mtk_free_fused(c);
-    mtk_free_layered(c);
+    mtk_free_fused(c, keep_ws);
+    mtk_free_layered(c, keep_ws);
     mtk_free_train(c);
     c->have_weights = false;
 }
@@ -291,33 +298,42 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
         if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_mlp_set_weights: W[%d] or b[%d] is null", i, i);
     hipStream_t s = (hipStream_t)stream;
     MTK_HIP(hipSetDevice(c->device));
-    // the previous image may still be in use by work queued on this stream
-    MTK_HIP(hipStreamSynchronize(s));
-    mtk_free_mlp(c);
+    // The old images go to the context's pool and come back as the new ones when the shapes are unchanged (mtk_common.h): the
+    // rewrite is then plain stream-ordered work - no allocation, no free, no synchronisation.  Blocks the LAST call left unclaimed
+    // (its shapes differed from the ones before) are freed now; work queued on this stream may still read them, hence the wait.
+    if (mtk_pool_has_stale(c, c->pool_gen)) {
+        MTK_HIP(hipStreamSynchronize(s));
+        mtk_pool_drain(c, c->pool_gen);
+    }
+    ++c->pool_gen;
+    if (c->train.attached) MTK_HIP(hipStreamSynchronize(s));  // the training image's buffers are freed outright
+    c->pooling = true;
+    struct Unpool { mtk_ctx* c; ~Unpool() { c->pooling = false; } } unpool{c};
+    mtk_free_mlp(c, true);
     c->dim_t = dim_t;
     c->n_hidden = n_hidden;
     c->hidden.assign(dims_host + 2, dims_host + 2 + n_hidden);
     const int tpad = round_up(dim_t, BN);
     int rc;
-    if ((rc = make_layer(c->proj, D, dim_t, round_up(D, BK), W[0], b[0], s))) return rc;
-    if ((rc = make_layer(c->temb0, dim_t, dim_t, tpad, W[1], b[1], s))) return rc;
-    if ((rc = make_layer(c->temb2, dim_t, dim_t, tpad, W[2], b[2], s))) return rc;
+    if ((rc = make_layer(c, c->proj, D, dim_t, round_up(D, BK), W[0], b[0], s))) return rc;
+    if ((rc = make_layer(c, c->temb0, dim_t, dim_t, tpad, W[1], b[1], s))) return rc;
+    if ((rc = make_layer(c, c->temb2, dim_t, dim_t, tpad, W[2], b[2], s))) return rc;
     c->blocks.resize(n_hidden);
     int prev = dim_t, prev_pad = tpad;
     for (int i = 0; i < n_hidden; ++i) {
-        if ((rc = make_layer(c->blocks[i], prev, c->hidden[i], prev_pad, W[3 + i], b[3 + i], s))) return rc;
+        if ((rc = make_layer(c, c->blocks[i], prev, c->hidden[i], prev_pad, W[3 + i], b[3 + i], s))) return rc;
         prev = c->hidden[i];
         prev_pad = c->blocks[i].out_pad;
     }
-    if ((rc = make_layer(c->head, prev, D, prev_pad, W[3 + n_hidden], b[3 + n_hidden], s))) return rc;
+    if ((rc = make_layer(c, c->head, prev, D, prev_pad, W[3 + n_hidden], b[3 + n_hidden], s))) return rc;
 
     // time-embedding table emb[t] = Linear2(SiLU(Linear0(sinusoid(t))))  (MODEL:608)
     const int Tpad = round_up(c->T, BM);
-    float *d_freq = nullptr, *e0 = nullptr, *e1 = nullptr;
-    MTK_HIP(hipMalloc(&d_freq, sizeof(float) * (dim_t / 2)));
-    MTK_HIP(hipMalloc(&e0, sizeof(float) * (size_t)Tpad * tpad));
-    MTK_HIP(hipMalloc(&e1, sizeof(float) * (size_t)Tpad * tpad));
-    MTK_HIP(hipMalloc(&c->d_emb, sizeof(float) * (size_t)Tpad * tpad));
+    float *d_freq = nullptr, *e0 = nullptr, *e1 = nullptr;  // scratch of this call: released to the pool, found there by the next call
+    if ((rc = mtk_alloc_t(c, &d_freq, sizeof(float) * (dim_t / 2)))) return rc;
+    if ((rc = mtk_alloc_t(c, &e0, sizeof(float) * (size_t)Tpad * tpad))) return rc;
+    if ((rc = mtk_alloc_t(c, &e1, sizeof(float) * (size_t)Tpad * tpad))) return rc;
+    if ((rc = mtk_alloc_t(c, &c->d_emb, sizeof(float) * (size_t)Tpad * tpad))) return rc;
     c->emb_ld = tpad;
     MTK_HIP(hipMemcpyAsync(d_freq, freqs_host, sizeof(float) * (dim_t / 2), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sinusoid, dim3(256), dim3(256), 0, s, e0, Tpad, tpad, c->T, dim_t, d_freq, c->d_label ? c->t_period : 0);
@@ -332,10 +348,9 @@ extern "C" int mtk_mlp_set_weights(mtk_ctx* c, int n_hidden, const int32_t* dims
         hipLaunchKernelGGL(k_add_label_rows, dim3(512), dim3(256), 0, s, c->d_emb, tpad, c->T, c->t_period, c->d_label, dim_t);
         MTK_HIP(hipGetLastError());
     }
-    MTK_HIP(hipStreamSynchronize(s));
-    (void)hipFree(d_freq);
-    (void)hipFree(e0);
-    (void)hipFree(e1);
+    mtk_release(c, d_freq);
+    mtk_release(c, e0);
+    mtk_release(c, e1);
     c->have_weights = true;
     if ((rc = mtk_pack_fused(c, s))) return rc;
     // split-bf16 weight images for MTK_PREC_BF16X3 (every shape); shapes the fused kernel does not cover also get plain bf16

@@ -1191,8 +1191,8 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     MTK_HIP(hipStreamSynchronize(s));
     for (auto& r : tr.layers) {
         if (r.l->owned) {
-            (void)hipFree(r.l->w32);
-            (void)hipFree(r.l->b32);
+            mtk_release(c, r.l->w32);
+            mtk_release(c, r.l->b32);
         }
         r.l->w32 = state + r.w_off;
         r.l->b32 = state + r.b_off;

@@ -80,6 +80,11 @@ class Engine:
         graph is only valid while this equals its value at capture time."""
         return int(_lib.lib().mtk_ctx_workspace_generation(self._h))
 
+    def alloc_count(self) -> int:
+        """hipMalloc calls made by the weight path so far (mtk_ctx_alloc_count): unchanged across a ``set_weights`` with the same
+        layer shapes."""
+        return int(_lib.lib().mtk_ctx_alloc_count(self._h))
+
     def set_seed_source(self, seed_row0: torch.Tensor | None) -> None:
         """``seed_row0``: int64 [2] device tensor {seed, row0} the reverse-chain kernels read instead of their arguments."""
         if seed_row0 is not None:

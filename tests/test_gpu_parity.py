@@ -1653,3 +1653,39 @@ def test_classifier_guidance_on_hip():
     close(got, want, rtol=RTOL, atol=max(1e-5, 3 * own))
     plain, _ = d.sample(targets.shape[0], torch.ones(3), _injected=dict(inj, y=torch.zeros(targets.shape[0], dtype=torch.long)))
     assert float((plain - want).abs().max()) > 1e-2  # the guidance moved the chain
+
+
+@pytest.mark.parametrize("tag,precision", [("M_mixed", "bf16"), ("B_ragged", "bf16x3"), ("B_ragged", "fp32")])
+def test_weight_update_with_unchanged_shapes_allocates_nothing(tag, precision):
+    """mtk_mlp_set_weights: a second call with the same layer shapes takes every block of the old images back
+    from the context's pool - the allocation counter does not move (no hipMalloc; nothing freed, nothing synchronised) - and the
+    denoiser then runs on the NEW weights, equal to a fresh context's output.  A later call with other shapes allocates again."""
+    import midst_toolkit_amd as mtk
+
+    c = load_case(tag)
+    d = build(c, precision=precision)
+    net = d.denoise_fn if hasattr(d, "denoise_fn") else d._denoise_fn
+    B = 700
+    x = torch.randn((B, c["D"]), device=dev())
+    t = torch.randint(0, c["T"], (B,), device=dev())
+    net.eval()
+    ng = torch.no_grad()
+    ng.__enter__()
+    first = net(x, t).clone()
+    eng = net._engine
+    n0 = eng.alloc_count()
+    for p in net.parameters():
+        p.mul_(1.01)
+    second = net(x, t).clone()          # sync_weights -> mtk_mlp_set_weights, same shapes
+    assert eng.alloc_count() == n0, "a same-shape weight update allocated"
+    assert not torch.equal(first, second)
+    fresh = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(c["d_layers"]), 0.0)).to(dev())
+    fresh.load_state_dict(net.state_dict(), strict=True)
+    fresh.precision = precision
+    fresh.eval()
+    assert torch.equal(fresh(x, t), second)
+    for p in net.parameters():          # and again: the scratch of the call is pooled too
+        p.mul_(0.99)
+    net(x, t)
+    assert eng.alloc_count() == n0
+    ng.__exit__(None, None, None)
