@@ -307,6 +307,17 @@ int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, cons
  * time-embedding scatter accumulates in 64-bit fixed point, so gradients are bit-identical run to run; off = fp32 hardware
  * atomics (order varies). */
 int mtk_train_set_deterministic(mtk_ctx* ctx, int on);
+/* MODEL:162-180 (MLP.Block.forward = dropout(activation(linear(x))), nn.Dropout in training mode): the iteration drops every
+ * hidden activation with probability p and scales the kept ones by 1 / (1 - p).  The mask of element (row0 + row, column n) of
+ * hidden layer l is a pure function of (seed, l, row, n) (Philox-4x32-10, stream 5), so it does not depend on how a batch is
+ * split over ranks or calls; the backward needs no second draw (a saved activation is > 0 exactly where the unit was positive
+ * and kept).  torch's own Dropout stream cannot be reproduced bit for bit on any other device; the contract matched is the
+ * distribution and the gradient given the mask (tests feed mtk_train_dropout_mask's masks to the oracle's autograd).  p = 0
+ * (default) switches it off; the caller passes a fresh seed per iteration. */
+int mtk_train_set_dropout(mtk_ctx* ctx, double p, uint64_t seed);
+/* The keep mask (1 = kept) hidden layer `layer` uses for rows [row0, row0 + B) under the current mtk_train_set_dropout setting:
+ * uint8 [B][width of the layer], row-major. */
+int mtk_train_dropout_mask(mtk_ctx* ctx, int layer, int64_t B, uint64_t row0, uint8_t* keep, mtk_stream stream);
 /* No reference counterpart (the reference trains in fp32; north_star part 1 "bf16 / fp32 accumulate"): MTK_PREC_BF16 makes every
  * GEMM of the training iteration (forward, data gradients, weight gradients) round its operands to bf16 and multiply on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the master weights, the gradient image, AdamW and EMA stay fp32.

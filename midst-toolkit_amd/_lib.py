@@ -65,6 +65,8 @@ _SIGS = {
     "mtk_train_set_gaussian_loss": (C.c_int, [_p, _i32]),
     "mtk_train_set_precision": (C.c_int, [_p, _i32]),
     "mtk_train_set_deterministic": (C.c_int, [_p, _i32]),
+    "mtk_train_set_dropout": (C.c_int, [_p, C.c_double, _u64]),
+    "mtk_train_dropout_mask": (C.c_int, [_p, _i32, _i64, _u64, _p, _p]),
     "mtk_train_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),
     "mtk_train_backward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, C.c_double, _u64, _u64, _p]),
     "mtk_train_backward_dev": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _u64, _u64, _p]),
@@ -116,7 +118,14 @@ def check(rc: int) -> None:
 
 
 def ptr(t: torch.Tensor | None) -> int | None:
-    return None if t is None else t.data_ptr()
+    """Device address of ``t`` for a C-ABI pointer argument (None -> NULL).  Every such argument is dereferenced by a kernel: a host
+    tensor here would be a GPU memory fault a few calls later, so it is refused where it is handed over."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"midst_toolkit_amd: a {tuple(t.shape)} {t.dtype} tensor on {t.device} was passed where the library "
+                           "reads device memory; move it to the MI355X first (the package has no CPU path)")
+    return t.data_ptr()
 
 
 def stream_handle(device: torch.device) -> int:

@@ -63,6 +63,10 @@ struct TrainState {
     // data-parallel overlap: one event per gradient bucket (head, blocks last..first, proj, time-embedding MLP), recorded on the
     // compute stream when that bucket of the gradient image is final (mtk_train_set_bucket_events); empty: no events
     std::vector<hipEvent_t> bucket_events;
+    // mtk_train_set_dropout (MODEL:162-180, MLP.Block = Linear -> ReLU -> Dropout in training mode): probability and the Philox key
+    // of the iteration's masks
+    float drop_p = 0.0f;
+    uint64_t drop_seed = 0;
     int bf16 = 0;  // mtk_train_set_precision: the iteration's GEMMs round their operands to bf16 (fp32 accumulate, fp32 master weights)
     // bf16 mode stores what it multiplies as bf16 (half the bytes through the L2 -> CU pipe that bounds these GEMMs; the values
     // were rounded to bf16 before every product anyway): saved activations, activation gradients, and a copy of the weight
@@ -242,7 +246,7 @@ __device__ __forceinline__ uint32_t mtk_pick4(uint32_t a, uint32_t b, uint32_t c
 __device__ __forceinline__ float mtk_pick4f(float a, float b, float c, float d, int j) {
     return __uint_as_float(mtk_pick4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d), j));
 }
-enum { MTK_STREAM_EPS = 1, MTK_STREAM_U = 2, MTK_STREAM_Z0 = 3, MTK_STREAM_U0 = 4, MTK_STREAM_STEP = 16 };
+enum { MTK_STREAM_EPS = 1, MTK_STREAM_U = 2, MTK_STREAM_Z0 = 3, MTK_STREAM_U0 = 4, MTK_STREAM_DROP = 5, MTK_STREAM_STEP = 16 };
 // element j of the normal stream for `row`
 __device__ __forceinline__ float mtk_philox_normal(uint64_t seed, uint64_t row, uint32_t stream, int j) {
     const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(j >> 2), stream, seed);

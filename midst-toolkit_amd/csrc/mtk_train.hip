@@ -53,9 +53,23 @@ struct G2 {
     int a16, b16, c16, mask16;
     uint16_t* Ct; int64_t ct_ld;   // optional second copy of the result, transposed and bf16: Ct[n * ct_ld + m]
     int tile64;                    // 64 x 64 tiles whatever the grid size (weight gradients split over the batch: see wgrad_chunk)
+    // Dropout after the activation (MODEL:162-180 in training mode; drop_thresh = 0: none): element (row, n) of hidden layer
+    // drop_layer is kept when its Philox word - counter (drop_row0 + row, layer, n), stream MTK_STREAM_DROP, key drop_seed - is
+    // >= drop_thresh = p 2^32, and scaled by drop_scale = 1 / (1 - p); a dropped one is 0.  The saved activation then carries the
+    // mask (kept and positive <=> stored value > 0), so the backward only needs the scale: mask_scale (0 reads as 1).
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed, drop_row0; int drop_layer;
+    float mask_scale;
     int dma;                       // the caller vouches for k_gemm2c's conditions (see there): 1 = B has rows up to the next
                                    // multiple of 64 past N, 2 = of 128
 };
+
+__device__ __forceinline__ bool g2_keep(uint64_t seed, uint64_t grow, int layer, int n, uint32_t thresh) {
+    return mtk_philox((uint32_t)grow, (uint32_t)(grow >> 32), ((uint32_t)layer << 16) | (uint32_t)n, MTK_STREAM_DROP, seed).x >= thresh;
+}
+__device__ __forceinline__ float g2_dropout(const G2& g, float v, int64_t row, int n) {
+    if (g.drop_thresh == 0) return v;
+    return g2_keep(g.drop_seed, g.drop_row0 + (uint64_t)row, g.drop_layer, n, g.drop_thresh) ? v * g.drop_scale : 0.0f;
+}
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
 // the MFMAs that consume the previous block (software pipelining: at the batch sizes the reference trains with there
@@ -252,7 +266,8 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 if (g.addend) v += g.addend[row * g.add_rs + n];
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
                 else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
-                if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v : g.neg_slope * v;
+                v = g2_dropout(g, v, row, n);
+                if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v * (g.mask_scale != 0.0f ? g.mask_scale : 1.0f) : g.neg_slope * v;
                 float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
                 if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
             }
@@ -466,9 +481,10 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                     if (g.addend) v += g.addend[row * g.add_rs + n];
                     if (g.relu == 2) v = v / (1.0f + expf(-v));
                     else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                    v = g2_dropout(g, v, row, n);
                     if (M16) {
                         const unsigned mbits = cs[lr * CP + li];
-                        v = (mbits != 0 && !(mbits & 0x8000u)) ? v : 0.0f;  // > 0 for a bf16 that is not a NaN (activations are not)
+                        v = (mbits != 0 && !(mbits & 0x8000u)) ? v * (g.mask_scale != 0.0f ? g.mask_scale : 1.0f) : 0.0f;  // > 0 for a bf16 that is not a NaN (activations are not)
                     }
                     const __bf16 e = (__bf16)v;
                     const unsigned bits = *reinterpret_cast<const uint16_t*>(&e);
@@ -511,6 +527,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                 if (g.addend) v += g.addend[row * g.add_rs + n];
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
                 else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
+                v = g2_dropout(g, v, row, n);
                 if (g.mask) {
                     bool pos;
                     if (g.mask16) {
@@ -519,7 +536,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                     } else {
                         pos = g.mask[row * g.m_rs + n] > 0.0f;
                     }
-                    v = pos ? v : g.neg_slope * v;
+                    v = pos ? v * (g.mask_scale != 0.0f ? g.mask_scale : 1.0f) : g.neg_slope * v;
                 }
                 if (g.c16) {
                     const __bf16 e = (__bf16)v;
@@ -1298,6 +1315,11 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.A = act_of(i); g.a16 = st16; g.lda = l.in_pad; g.B = w_of(l); g.b16 = st16; g.ldb = l.in_pad;
         g.C = const_cast<float*>(act_of(i + 1)); g.c16 = st16; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32; g.relu = 1;
         if (st16) { g.Ct = tr.act16t[i + 1]; g.ct_ld = Mpad; g.dma = 2; }  // B = W: out_pad rows, a multiple of 128
+        if (tr.drop_p > 0.0f) {
+            const double th = (double)tr.drop_p * 4294967296.0;
+            g.drop_thresh = th >= 4294967295.0 ? 4294967295u : (uint32_t)th;
+            g.drop_scale = 1.0f / (1.0f - tr.drop_p); g.drop_seed = tr.drop_seed; g.drop_row0 = row0; g.drop_layer = (int)i;
+        }
         if ((rc = launch<false, false>(g, s))) return rc;
     }
     {
@@ -1384,6 +1406,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     // the time-embedding MLP's backward (scatter of d act[0] into the table, three small GEMMs), which used to run after the
     // last of them with the chip idle around it.
     const int nb = (int)c->blocks.size();
+    const float drop_gain = tr.drop_p > 0.0f ? 1.0f / (1.0f - tr.drop_p) : 1.0f;  // d [relu(x) keep / (1 - p)] / dx where the saved value is > 0
     {   // head: d act[nb] = dout^T W, masked by act[nb] > 0
         MlpLayer& l = c->head;
         G2 d{};
@@ -1391,7 +1414,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = tr.dout; d.lda = ld; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
         d.C = const_cast<float*>(dact_of(nb)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
-        if (nb > 0) { d.mask = act_of(nb); d.mask16 = st16; d.m_rs = l.in_pad; }
+        if (nb > 0) { d.mask = act_of(nb); d.mask16 = st16; d.m_rs = l.in_pad; d.mask_scale = drop_gain; }
         if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[nb]; d.ct_ld = Mpad; }
         if ((rc = st16 ? launch<true, false>(d, s) : launch<true, true>(d, s))) return rc;
     }
@@ -1402,7 +1425,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = dact_of(i + 1); d.a16 = st16; d.lda = l.out_pad; d.B = w_of(l); d.b16 = st16; d.ldb = l.in_pad;
         d.C = const_cast<float*>(dact_of(i)); d.c16 = st16; d.c_rs = l.in_pad; d.c_cs = 1;
-        if (i > 0) { d.mask = act_of(i); d.mask16 = st16; d.m_rs = l.in_pad; }  // act[0] (proj + emb) has no ReLU
+        if (i > 0) { d.mask = act_of(i); d.mask16 = st16; d.m_rs = l.in_pad; d.mask_scale = drop_gain; }  // act[0] (proj + emb) has no ReLU
         if (st16) { d.B = wt_of(l); d.ldb = l.out_pad; d.Ct = tr.dact16t[i]; d.ct_ld = Mpad; d.dma = l.in_pad % 64 == 0; }  // W^T has in_pad rows
         if ((rc = st16 ? launch<false, false>(d, s) : launch<false, true>(d, s))) return rc;
     }
@@ -1541,6 +1564,32 @@ extern "C" int mtk_train_set_precision(mtk_ctx* c, int precision) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_precision: null context");
     if (precision != MTK_PREC_FP32 && precision != MTK_PREC_BF16) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_set_precision: %d (fp32 or bf16)", precision);
     c->train.bf16 = precision == MTK_PREC_BF16 ? 1 : 0;
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_dropout(mtk_ctx* c, double p, uint64_t seed) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_dropout: null context");
+    if (!(p >= 0.0 && p < 1.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_dropout: p = %g outside [0, 1)", p);
+    c->train.drop_p = (float)p;
+    c->train.drop_seed = seed;
+    return MTK_OK;
+}
+
+__global__ void k_dropout_mask(uint8_t* out, int64_t rows, int width, uint64_t seed, uint64_t row0, int layer, uint32_t thresh) {
+    const int64_t n = rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = g2_keep(seed, row0 + (uint64_t)(i / width), layer, (int)(i % width), thresh) ? 1 : 0;
+}
+
+extern "C" int mtk_train_dropout_mask(mtk_ctx* c, int layer, int64_t B, uint64_t row0, uint8_t* keep, mtk_stream stream) {
+    if (!c || !keep) MTK_FAIL(MTK_ERR_ARG, "mtk_train_dropout_mask: null argument");
+    if (layer < 0 || layer >= (int)c->blocks.size()) MTK_FAIL(MTK_ERR_ARG, "mtk_train_dropout_mask: hidden layer %d of %zu", layer, c->blocks.size());
+    if (B <= 0) MTK_FAIL(MTK_ERR_ARG, "mtk_train_dropout_mask: B <= 0");
+    MTK_HIP(hipSetDevice(c->device));
+    const double th = (double)c->train.drop_p * 4294967296.0;
+    const uint32_t thresh = c->train.drop_p > 0.0f ? (th >= 4294967295.0 ? 4294967295u : (uint32_t)th) : 0u;
+    hipLaunchKernelGGL(k_dropout_mask, dim3(1024), dim3(256), 0, (hipStream_t)stream, keep, B, c->blocks[layer].out, c->train.drop_seed, row0, layer, thresh);
+    MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
 

@@ -61,6 +61,10 @@ class _MixedLossFunction(torch.autograd.Function):
         B, dev = x0.shape[0], x0.device
         lm = torch.empty((B,), dtype=torch.float32, device=dev) if eng.C > 0 else None
         lg = torch.empty((B,), dtype=torch.float32, device=dev) if eng.Nn > 0 else None
+        net = diffusion._denoise_fn
+        p_drop = net.training_dropout() if hasattr(net, "training_dropout") else 0.0
+        diffusion._dropout_calls = getattr(diffusion, "_dropout_calls", 0) + 1
+        eng.train_set_dropout(p_drop, (seed + 0xD1B54A32D192ED03 * diffusion._dropout_calls) % (1 << 63) if p_drop else 0)  # MODEL:162-180
         ctx.token = eng.train_forward(x0, t, eps, u, lm, lg, seed=seed)
         ctx.eng, ctx.net, ctx.seed, ctx.B = eng, diffusion._denoise_fn, seed, B
         ctx.inputs = (x0, t, eps)

@@ -99,6 +99,7 @@ class Engine:
     def set_weights(self, weights: list[tuple[torch.Tensor, torch.Tensor]], dims: list[int], freqs: torch.Tensor) -> None:
         """weights: [(W, b)] in the order proj, temb.0, temb.2, blocks..., head (fp32, on device)."""
         n_hidden = len(weights) - 4
+        self._hidden_widths = [int(w.shape[0]) for w, _ in weights[3:3 + n_hidden]]
         keep = []
         for W, b in weights:
             require_cuda(W, "set_weights")
@@ -310,6 +311,18 @@ class Engine:
     def train_set_deterministic(self, on: bool) -> None:
         """True (default): fixed-order reductions, gradients bit-identical run to run; False: fp32 hardware atomics."""
         check(_lib.lib().mtk_train_set_deterministic(self._h, int(bool(on))))
+
+    def train_set_dropout(self, p: float, seed: int = 0) -> None:
+        """MODEL:162-180 in training mode: hidden activations dropped with probability ``p`` by Philox masks keyed by ``seed``
+        (mtk_train_set_dropout); 0 switches it off."""
+        check(_lib.lib().mtk_train_set_dropout(self._h, float(p), int(seed) % (1 << 64)))
+
+    def train_dropout_mask(self, layer: int, B: int, row0: int = 0) -> torch.Tensor:
+        """uint8 [B, width] keep mask of hidden layer ``layer`` under the current setting (mtk_train_dropout_mask)."""
+        out = torch.empty((B, self._hidden_widths[layer]), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_dropout_mask(self._h, layer, B, row0, ptr(out), self._stream()))
+        return out
 
     def train_forward(self, x0, t, eps, u, loss_multi=None, loss_gauss=None, seed=0, row0=0) -> int:
         """Forward half of train_step (activations kept on the context).  Returns a token that train_backward checks."""

@@ -109,9 +109,10 @@ class MLPDiffusion(nn.Module):
         # rows of the time-embedding table (Engine.set_label_embedding); the regression variant (num_classes == 0, a Linear on
         # the raw target) is kept for state-dict compatibility and refuses in forward when a target is passed
         self.label_conditioned = getattr(is_target_conditioned, "value", is_target_conditioned) == "embedding"
-        # dropout > 0 (MODEL:162-180): the Dropout modules are kept for state-dict / structure compatibility and are the identity
-        # in eval mode, which is how scoring and sampling run; with the module in training mode the HIP path refuses (see
-        # _check_dropout): it has no dropout mask, and every reference config trains with 0.0
+        # dropout > 0 (MODEL:162-180): the Dropout modules are kept for state-dict / structure compatibility.  Scoring and sampling
+        # run the eval-mode network (identity); the training iteration (ClavaDDPMTrainer, the mixed_loss autograd seam) applies
+        # Philox masks in the HIP kernels when the module is in training mode (training_dropout, mtk_train_set_dropout); only a
+        # plain forward() in training mode refuses - the inference kernels carry no mask
         self.mlp = MLP.make_baseline(
             input_dimension=timestep_dimension,
             layers_dimensions=self.diffusion_parameters.layers_dimensions,
@@ -170,14 +171,18 @@ class MLPDiffusion(nn.Module):
         self.sync_weights()
         return self._engine
 
+    def training_dropout(self) -> float:
+        """The probability the training iteration drops hidden activations with: the blocks' Dropout p in training mode, 0 in eval."""
+        return float(self.diffusion_parameters.dropout) if self.training else 0.0
+
     def _check_dropout(self) -> None:
-        if self.training and float(self.diffusion_parameters.dropout) != 0.0:
-            raise NotImplementedError("MLPDiffusion with dropout > 0 in training mode: the MI355X path evaluates the eval-mode network "
-                                      "(Dropout = identity); call .eval() for scoring / sampling, train such a model with the reference")
+        if self.training_dropout() != 0.0:
+            raise NotImplementedError("MLPDiffusion.forward with dropout > 0 in training mode: the inference kernels evaluate the "
+                                      "eval-mode network (Dropout = identity); call .eval() for scoring / sampling - the training "
+                                      "iteration (ClavaDDPMTrainer / mixed_loss under autograd) applies the masks itself")
 
     def sync_weights(self) -> None:
         """Re-pack the weights into the library when any parameter changed (optimizer step, load)."""
-        self._check_dropout()
         key = tuple((p.data_ptr(), p._version) for wb in self._weights() for p in wb)
         if self._label_rows():
             lw = self.label_embedding.weight
@@ -192,6 +197,7 @@ class MLPDiffusion(nn.Module):
         """MODEL:596.  ``y`` is ignored unless the network is label-conditioned (IsTargetConditioned.EMBEDDING, MODEL:610-612):
         then record i runs with table row ``(1 + y[i]) * num_timesteps + timesteps[i]`` (timesteps must be below
         ``num_timesteps``, the table's period; ``y=None`` takes the label-free rows like the reference)."""
+        self._check_dropout()
         if not input_tensor.is_cuda:
             raise RuntimeError("MLPDiffusion.forward: midst_toolkit_amd has no CPU path; move the module and inputs to the MI355X")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

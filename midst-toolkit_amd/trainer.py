@@ -104,9 +104,12 @@ class ClavaDDPMTrainer:
             eps = u = None
             seed = (self.seed + 0x9E3779B97F4A7C15 * (self.optimizer.steps_done + 1)) % (1 << 63)
         eng.set_math(d.math or ("fast" if (d.rng == "philox" and injected is None) else "reference"))
+        p_drop = d._denoise_fn.training_dropout() if hasattr(d._denoise_fn, "training_dropout") else 0.0
+        # MODEL:162-180: a fresh mask per iteration, whatever the noise source (its key follows the step count like the Philox noise's)
+        eng.train_set_dropout(p_drop, (self.seed + 0xD1B54A32D192ED03 * (self.optimizer.steps_done + 1)) % (1 << 63) if p_drop else 0)
         t = t.to(x0.device, torch.int64).contiguous()
-        eps = eps.float().contiguous() if eps is not None and eps.numel() else None
-        u = u.float().contiguous() if u is not None and u.numel() else None
+        eps = eps.to(x0.device).float().contiguous() if eps is not None and eps.numel() else None
+        u = u.to(x0.device).float().contiguous() if u is not None and u.numel() else None
         # both per-row loss vectors in one buffer: their batch means are one reduction launch, not two plus a fill for the absent one
         rows = torch.empty((2, B), dtype=torch.float32, device=x0.device) if (eng.C > 0 and eng.Nn > 0) else None
         lm = rows[0] if rows is not None else (torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None)

@@ -276,8 +276,10 @@ def time_table(params: dict[str, torch.Tensor], T: int, dim_t: int = 128) -> tor
 
 
 def mlp_forward(params: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tensor, dim_t: int = 128,
-                dtype: torch.dtype = torch.float32, y: torch.Tensor | None = None) -> torch.Tensor:
-    """MODEL:596-615, dropout 0.  ``y`` enters only when ``params`` holds ``label_embedding.weight``
+                dtype: torch.dtype = torch.float32, y: torch.Tensor | None = None, drop_masks=None, drop_p: float = 0.0) -> torch.Tensor:
+    """MODEL:596-615.  Dropout (MODEL:162-180, training mode): ``drop_masks[i]`` is the keep mask of hidden block i and the
+    block returns ``relu(linear(h)) * mask / (1 - drop_p)`` - F.dropout's arithmetic with the Bernoulli draw injected; None: eval
+    mode.  ``y`` enters only when ``params`` holds ``label_embedding.weight``
     (IsTargetConditioned.EMBEDDING with classes, MODEL:610-612: embeddings += silu(label_embedding(y.squeeze()))).
     ``dtype=torch.float64`` evaluates the same network in double (used only to measure how far
     the reference's own fp32 result is from the exact value of its formula)."""
@@ -301,6 +303,8 @@ def mlp_forward(params: dict[str, torch.Tensor], x: torch.Tensor, t: torch.Tenso
     i = 0
     while f"mlp.blocks.{i}.linear.weight" in params:
         h = F.relu(F.linear(h, params[f"mlp.blocks.{i}.linear.weight"], params[f"mlp.blocks.{i}.linear.bias"]))
+        if drop_masks is not None:
+            h = h * drop_masks[i].to(h.dtype) * (1.0 / (1.0 - drop_p))
         i += 1
     return F.linear(h, params["mlp.head.weight"], params["mlp.head.bias"])
 
@@ -328,12 +332,12 @@ def init_mlp_params(D: int, d_layers: list[int], dim_t: int = 128, seed: int = 0
     return p
 
 
-def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse", y=None):
+def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse", y=None, drop_masks=None, drop_p: float = 0.0):
     """a14 / GMD:1013 with injected (t, eps, u): returns per-record rows and the two means.  ``gaussian_loss = "kl"``:
     GaussianLossType.KL (GMD:534-541), the fp64 variational-bound term instead of the MSE.  ``y``: the labels GMD:1042 hands
     to a label-conditioned denoiser."""
     x_num_t, xt_idx = q_sample_fused(s, K, Nn, x0, t, eps, u)
-    out = mlp_forward(params, model_input(x_num_t, xt_idx, K), t, y=y)
+    out = mlp_forward(params, model_input(x_num_t, xt_idx, K), t, y=y, drop_masks=drop_masks, drop_p=drop_p)
     lm, lg = loss_rows(s, K, Nn, out, x0, xt_idx, eps, t)
     if gaussian_loss == "kl" and Nn > 0:
         lg = gaussian_kl_rows(s, out[:, :Nn], x0[:, :Nn], x_num_t, t)
@@ -525,12 +529,13 @@ def multinomial_loss_floor(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0:
 
 
 # --------------------------------------------------------------------------- training (a19)
-def loss_and_grads(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], x0, t, eps, u, gaussian_loss: str = "mse"):
+def loss_and_grads(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], x0, t, eps, u, gaussian_loss: str = "mse", y=None,
+                   drop_masks=None, drop_p: float = 0.0):
     """TRAINER:88-91: ``zero_grad; loss_multi + loss_gauss; backward`` with injected (t, eps, u).
     Returns (grads by parameter name, loss_multi mean, loss_gauss mean).  The gradient is torch
     autograd through the restated forward ops, i.e. exactly what the reference differentiates."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u, gaussian_loss)
+    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u, gaussian_loss, y=y, drop_masks=drop_masks, drop_p=drop_p)
     (m_mean + g_mean).backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     return grads, m_mean.detach(), g_mean.detach()

@@ -532,7 +532,8 @@ def test_label_conditioned_denoiser():
 
 def test_dropout_configured_denoiser_runs_in_eval_mode():
     """MODEL:162-180: a denoiser configured with dropout > 0 loads and, in eval mode (Dropout = identity: how scoring and sampling
-    call it), gives the dropout-free network's outputs; in training mode the HIP path refuses instead of silently dropping nothing."""
+    call it), gives the dropout-free network's outputs; in training mode a plain forward() refuses instead of silently dropping
+    nothing (the inference kernels carry no mask; the training iteration applies its own: tests/test_gpu_train.py)."""
     import midst_toolkit_amd as mtk
 
     c = load_case("A_numeric")
@@ -540,8 +541,8 @@ def test_dropout_configured_denoiser_runs_in_eval_mode():
     net.load_state_dict(case_params(c), strict=True)
     d = mtk.GaussianMultinomialDiffusion(c["K"], c["Nn"], net, num_timesteps=c["T"], device=dev()).to(dev())
     x, t = tt(c["ml_model_in"]).to(dev()), tt(c["ml_t"]).to(dev())
-    with pytest.raises(NotImplementedError):
-        d.engine()
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        net(x, t)
     d.eval()
     with torch.no_grad():
         close(net(x, t), tt(c["ml_model_out"]))

@@ -222,6 +222,84 @@ def test_iteration_needs_no_memset_of_its_buffers(precision):
     assert all(torch.equal(a, b) for a, b in zip(clean, after_big))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,p", [("fp32", 0.1), ("fp32", 0.5), ("bf16", 0.25)])
+def test_dropout_in_the_training_iteration(precision, p):
+    """MODEL:162-180 (MLP.Block = Linear -> ReLU -> Dropout, training mode; VERDICT r2 missing 2).  torch's Bernoulli stream cannot
+    be matched off-device, so the mask is the library's own Philox draw, and what is checked is everything that follows from it:
+    given the masks (mtk_train_dropout_mask), losses and every gradient tensor equal the oracle's autograd through
+    relu(linear) * mask / (1 - p) at the tolerance of the precision; the keep rate is 1 - p; the masks move with the seed and do
+    not depend on how the rows are split over calls (row0); p = 0 restores the plain iteration bit for bit."""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[256, 512, 256])
+    B = 1500
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    # kept units are scaled by 1 / (1 - p): at random init the head then puts out logits in the hundreds and the loss is so badly
+    # conditioned that fp32 rounding alone moves the gradients by 5e-3 (measured, p = 0.5); a head scaled down keeps the comparison
+    # about the masks (fp32 cases; the bf16 case keeps the plain head, its 3e-2 bar is relative to full-size gradients)
+    if precision == "fp32":
+        p0["mlp.head.weight"], p0["mlp.head.bias"] = p0["mlp.head.weight"] * 0.05, p0["mlp.head.bias"] * 0.05
+    x0, t, eps, u = big_batch(c, B)
+    s = orc.make_schedule(c["T"], "cosine")
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    eng.train_set_precision(precision)
+    lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+    args = (x0.to(dev()), t.to(dev()), eps.to(dev()), u.to(dev()), 1.0 / B, lm, lg)
+    eng.train_step(*args)
+    plain = tr.state[1].clone()
+    eng.train_set_dropout(p, seed=1234)
+    eng.train_step(*args, row0=64)
+    got = export(tr, "grads")
+    masks = [eng.train_dropout_mask(i, B, row0=64).cpu() for i in range(3)]
+    for m in masks:
+        assert abs(float(m.float().mean()) - (1 - p)) < 0.01
+    # the same rows as two calls' worth of row offsets; another seed gives another mask
+    assert torch.equal(eng.train_dropout_mask(1, 500, row0=64 + 1000).cpu(), masks[1][1000:])
+    eng.train_set_dropout(p, seed=1235)
+    assert not torch.equal(eng.train_dropout_mask(1, B, row0=64).cpu(), masks[1])
+    want, lm_ref, lg_ref = orc.loss_and_grads(s, c["K"], c["Nn"], p0, x0, t, eps, u, drop_masks=masks, drop_p=p)
+    tol_l, tol_g = (2e-4, 4e-4) if precision == "fp32" else (2e-3, 3e-2)  # measured: 2.1e-4 worst gradient tensor at p = 0.5 in fp32
+    assert abs(float(lg.mean()) - float(lg_ref)) <= tol_l * abs(float(lg_ref)) + 1e-7 and abs(float(lm.mean()) - float(lm_ref)) <= tol_l * abs(float(lm_ref)) + 1e-7
+    for k in want:
+        num, den = float((got[k].double() - want[k].double()).norm()), float(want[k].double().norm())
+        assert num <= tol_g * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+    eng.train_set_dropout(0.0)
+    eng.train_step(*args)
+    assert torch.equal(tr.state[1], plain)
+
+
+@pytest.mark.gpu
+def test_trainer_applies_dropout_in_training_mode_only():
+    """A denoiser built with dropout > 0 (MODEL:576-582): the trainer's iteration draws a fresh mask per step while the module is
+    in training mode and none in eval mode; a plain forward() in training mode still refuses (the inference kernels carry no mask)."""
+    import midst_toolkit_amd as mtk
+
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[256, 256])
+    x0, t, eps, u = big_batch(c, 512)
+
+    def run(train_mode):
+        torch.manual_seed(0)
+        net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(c["d_layers"]), 0.3))
+        net.load_state_dict(orc.init_mlp_params(c["D"], c["d_layers"], seed=0), strict=True)
+        net.train(train_mode)
+        d = mtk.GaussianMultinomialDiffusion(np.asarray(c["K"]), c["Nn"], net, num_timesteps=c["T"], device=dev()).to(dev())
+        net.train(train_mode)
+        tr = mtk.ClavaDDPMTrainer(d, iter(()), 2e-3, 1e-4, 10, device=dev())
+        losses = [tuple(float(v) for v in tr._train_step(x0, injected=(t, eps, u))) for _ in range(3)]
+        return net, losses
+
+    net_eval, eval_losses = run(False)
+    net_train, train_losses = run(True)
+    assert all(np.isfinite(v) for pair in train_losses for v in pair)
+    assert train_losses[0] != eval_losses[0]              # the first step already sees a mask
+    _, again = run(True)
+    assert again == train_losses                          # and the masks follow the trainer's seed and step count
+    with torch.no_grad():
+        net_eval(x0[:8, :].to(dev()), t[:8].to(dev()))
+        with pytest.raises(NotImplementedError):
+            net_train(x0[:8, :].to(dev()), t[:8].to(dev()))
+
+
 def test_bf16_training_berka_run():
     """The 200-step Berka run of test_berka_run_200_steps with the bf16 training GEMMs.  Stated tolerance on the loss curve against
     the fp32 reference curve: the first 10 losses within 5e-3, mean deviation <= 4e-2 and max <= 2e-1 over the 200 steps (measured
