@@ -66,9 +66,10 @@ struct G2 {
 __device__ __forceinline__ bool g2_keep(uint64_t seed, uint64_t grow, int layer, int n, uint32_t thresh) {
     return mtk_philox((uint32_t)grow, (uint32_t)(grow >> 32), ((uint32_t)layer << 16) | (uint32_t)n, MTK_STREAM_DROP, seed).x >= thresh;
 }
-__device__ __forceinline__ float g2_dropout(const G2& g, float v, int64_t row, int n) {
-    if (g.drop_thresh == 0) return v;
-    return g2_keep(g.drop_seed, g.drop_row0 + (uint64_t)row, g.drop_layer, n, g.drop_thresh) ? v * g.drop_scale : 0.0f;
+// (scalars, not the argument struct by reference: that put a copy of the struct into scratch memory in the 128-tile kernels)
+__device__ __forceinline__ float g2_dropout(uint32_t thresh, float scale, uint64_t seed, uint64_t grow, int layer, float v, int n) {
+    if (thresh == 0) return v;
+    return g2_keep(seed, grow, layer, n, thresh) ? v * scale : 0.0f;
 }
 
 // One operand tile (T rows x 32 k) moves global -> registers -> LDS; the registers are loaded one k-block ahead of
@@ -159,7 +160,7 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(const float* f) {
 // they feed sixteen v_mfma_f32_32x32x2f32, rounded to bf16 they are the operands of two v_mfma_f32_32x32x16_bf16 (any
 // assignment of k values to lanes is valid as long as both operands use the same one).  Master weights, gradients,
 // AdamW and EMA stay fp32.
-template <bool AT, bool BT, int WT, bool BF>
+template <bool AT, bool BT, int WT, bool BF, bool DROP = false>  // DROP: the forward GEMM of a hidden layer under dropout (its own instantiation: the Philox block per element costs the others nothing)
 __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
     constexpr int T = 64 * WT;
     constexpr int TILE_FLOATS = T * LDN > TK * (T + 4) ? T * LDN : TK * (T + 4);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 if (g.addend) v += g.addend[row * g.add_rs + n];
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
                 else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
-                v = g2_dropout(g, v, row, n);
+                if constexpr (DROP) v = g2_dropout(g.drop_thresh, g.drop_scale, g.drop_seed, g.drop_row0 + (uint64_t)row, g.drop_layer, v, n);
                 if (g.mask) v = (g.mask[row * g.m_rs + n] > 0.0f) ? v * (g.mask_scale != 0.0f ? g.mask_scale : 1.0f) : g.neg_slope * v;
                 float* dst = (g.slab ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.C) + row * g.c_rs + (int64_t)n * g.c_cs;
                 if (g.atomic && !g.slab) unsafeAtomicAdd(dst, v); else *dst = v;
@@ -426,7 +427,7 @@ struct TileMoverB<TR, T, true> {
 // What follows the k-loop of the bf16 GEMMs (k_gemm2b, k_gemm2c): bias-gradient row sums, then the result tile.  `smem` is the
 // kernel's LDS, free by now (the caller's loop ends with a barrier), at least 4 * 2 * 32 * 40 elements.
 // Wave layout: (waves / 2) x 2, wave (wr, wc) owns MT x NT sub-tiles of 32 x 32 from row 32 MT wr, column 32 NT wc of the tile.
-template <int MT, int NT>
+template <int MT, int NT, bool DROP>
 __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT], float (&rs)[MT], bool sum_rows, uint16_t* smem,
                                               int64_t m0, int n0, int lane, int wid) {
     constexpr int CP = 40;  // pitch (elements) of a wave's 32 x 32 staging tiles: 80-byte rows, 16-byte aligned
@@ -481,7 +482,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                     if (g.addend) v += g.addend[row * g.add_rs + n];
                     if (g.relu == 2) v = v / (1.0f + expf(-v));
                     else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
-                    v = g2_dropout(g, v, row, n);
+                    if constexpr (DROP) v = g2_dropout(g.drop_thresh, g.drop_scale, g.drop_seed, g.drop_row0 + (uint64_t)row, g.drop_layer, v, n);
                     if (M16) {
                         const unsigned mbits = cs[lr * CP + li];
                         v = (mbits != 0 && !(mbits & 0x8000u)) ? v * (g.mask_scale != 0.0f ? g.mask_scale : 1.0f) : 0.0f;  // > 0 for a bf16 that is not a NaN (activations are not)
@@ -527,7 +528,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                 if (g.addend) v += g.addend[row * g.add_rs + n];
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
                 else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
-                v = g2_dropout(g, v, row, n);
+                if constexpr (DROP) v = g2_dropout(g.drop_thresh, g.drop_scale, g.drop_seed, g.drop_row0 + (uint64_t)row, g.drop_layer, v, n);
                 if (g.mask) {
                     bool pos;
                     if (g.mask16) {
@@ -558,7 +559,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
         }
 }
 
-template <bool AT, bool BT, int WT, bool A16, bool B16>
+template <bool AT, bool BT, int WT, bool A16, bool B16, bool DROP = false>
 __global__ __launch_bounds__(256) void k_gemm2b(G2 g) {
     constexpr int T = 64 * WT;
     constexpr int kSmem = 2 * T * PITCH2 > 4 * 2 * 32 * 40 ? 2 * T * PITCH2 : 4 * 2 * 32 * 40;  // the epilogue stages 32 x 32 tiles here
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void k_gemm2b(G2 g) {
         }
         __syncthreads();
     }
-    gemm2b_finish<WT, WT>(g, acc, rs, sum_rows, smem, m0, n0, lane, wid);
+    gemm2b_finish<WT, WT, DROP>(g, acc, rs, sum_rows, smem, m0, n0, lane, wid);
 }
 
 // The GEMM most of a bf16 iteration runs in: both operands bf16, both read along their rows (the transposed copies exist for
@@ -638,7 +639,7 @@ extern __shared__ __attribute__((aligned(16))) uint16_t g2c_smem[];
 // per CU); <4, 1, 2> = 128 x 128 tiles, 8 waves, 128 KiB.  With 64 x 64 tiles a 2,048 x 1,024 x 1,024 product pulls 134 MB out of
 // the L2s and runs at their ~11 TB/s (12 us whatever the latency hiding); 128 x 128 halves the traffic.  Every wave moves two
 // 8-row pieces of each operand per k-step in both shapes.
-template <int WR, int MT, int NT>
+template <int WR, int MT, int NT, bool DROP = false>
 __global__ __launch_bounds__(WR * 128) void k_gemm2c(G2 g) {
     constexpr int TM_ = WR * 32 * MT, TN_ = 2 * 32 * NT, NW = WR * 2;
     constexpr int PA = TM_ / 8 / NW, PB = TN_ / 8 / NW;  // 8-row pieces per wave and k-step
@@ -730,26 +731,32 @@ __global__ __launch_bounds__(WR * 128) void k_gemm2c(G2 g) {
         }
     }
     __syncthreads();  // the ring is free: the epilogue stages its tiles in it
-    gemm2b_finish<MT, NT>(g, acc, rs, sum_rows, g2c_smem, m0, n0, lane, wid);
+    gemm2b_finish<MT, NT, DROP>(g, acc, rs, sum_rows, g2c_smem, m0, n0, lane, wid);
 }
 
-template <int WR, int MT, int NT>
+template <int WR, int MT, int NT, bool DROP = false>
 int launch_c(const G2& g, dim3 grid, hipStream_t s) {
     constexpr int kBytes = kRing * (WR * 32 * MT + 64 * NT) * 128;
     static bool attr_set[64] = {};
     int dev = 0;
     MTK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        MTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2c<WR, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+        MTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2c<WR, MT, NT, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_gemm2c<WR, MT, NT>), grid, dim3(WR * 128), kBytes, s, g);
+    hipLaunchKernelGGL((k_gemm2c<WR, MT, NT, DROP>), grid, dim3(WR * 128), kBytes, s, g);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
 
 template <bool AT, bool BT, int WT>
 void launch_b(const G2& g, dim3 grid, hipStream_t s) {
+    if constexpr (!AT && !BT) {  // hidden-layer forward under dropout: bf16 activations times bf16 weights
+        if (g.drop_thresh != 0 && g.a16 && g.b16) {
+            hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, true, true, true>), grid, dim3(256), 0, s, g);
+            return;
+        }
+    }
     if (g.a16 && g.b16) hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, true, true>), grid, dim3(256), 0, s, g);
     else if (g.a16) hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, true, false>), grid, dim3(256), 0, s, g);
     else if (g.b16) hipLaunchKernelGGL((k_gemm2b<AT, BT, WT, false, true>), grid, dim3(256), 0, s, g);
@@ -768,15 +775,23 @@ int launch(const G2& g, hipStream_t s) {
         // measured (2,048 and 8,192 rows x 1,024 x 1,024): the 128 x 128 shape is no faster in the loop and slower at 128 workgroups
         const bool big = force_wt == 2;
         // a 128-wide B tile reads rows up to the next multiple of 128 past N: the caller's `dma` covers multiples of 64 only
-        if (big && (g.N % 128 == 0 || g.dma == 2)) return launch_c<4, 1, 2>(g, g128, s);
-        return launch_c<2, 1, 1>(g, g64, s);
+        if (big && (g.N % 128 == 0 || g.dma == 2)) return g.drop_thresh != 0 ? launch_c<4, 1, 2, true>(g, g128, s) : launch_c<4, 1, 2>(g, g128, s);
+        return g.drop_thresh != 0 ? launch_c<2, 1, 1, true>(g, g64, s) : launch_c<2, 1, 1>(g, g64, s);
     }
     if (wg128 >= 512 && !g.tile64) {
         if (g.bf16 && !old_bf) launch_b<AT, BT, 2>(g, g128, s);
+        else if (g.drop_thresh != 0 && !AT && !BT) {
+            if (g.bf16) hipLaunchKernelGGL((k_gemm2<false, false, 2, true, true>), g128, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((k_gemm2<false, false, 2, false, true>), g128, dim3(256), 0, s, g);
+        }
         else if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 2, true>), g128, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_gemm2<AT, BT, 2, false>), g128, dim3(256), 0, s, g);
     } else {
         if (g.bf16 && !old_bf) launch_b<AT, BT, 1>(g, g64, s);
+        else if (g.drop_thresh != 0 && !AT && !BT) {
+            if (g.bf16) hipLaunchKernelGGL((k_gemm2<false, false, 1, true, true>), g64, dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((k_gemm2<false, false, 1, false, true>), g64, dim3(256), 0, s, g);
+        }
         else if (g.bf16) hipLaunchKernelGGL((k_gemm2<AT, BT, 1, true>), g64, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((k_gemm2<AT, BT, 1, false>), g64, dim3(256), 0, s, g);
     }

@@ -4,6 +4,9 @@
 #   2. separate --pmc passes (FETCH_SIZE; WRITE_SIZE) of the same command, short    -> gpurun_out/<tag>/pmc_bench_{fetch,write}/
 #   3. --kernel-trace --stats of benchmarks/bench_train_sample.py --train-only      -> gpurun_out/<tag>/train_*_kernel_stats.csv
 #   4. --pmc passes of benchmarks/bench_kernels.py (the three HBM kernels)          -> gpurun_out/<tag>/pmc_kernels_{fetch,write}/
+#   5. the training iteration at config 5's per-rank shape (2,048 x 4x1024, bf16), kernel stats and plain timings
+#   6. the layered 4x1024 denoiser in chain mode (one timestep per launch): kernel stats and --pmc FETCH_SIZE / WRITE_SIZE passes
+#   7. small-batch reverse chains (1,024 / 8,192 rows, eager vs graph) and the state-input vs matrix-input chain
 # Each step runs under its own time limit; a step that times out or aborts ends the script.
 set -uo pipefail
 tag=${1:-prof}
@@ -25,6 +28,15 @@ grep '^{' "$out/bench_stats.log" | tail -n 1 > "$out/bench.json"
 step pmc_bench_fetch 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_bench_fetch" -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras
 step pmc_bench_write 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_bench_write" -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras
 step train_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_stats" -o train -- python3 "$root/benchmarks/bench_train_sample.py" --train-only
+step train1024_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train1024_stats" -o train1024 -- python3 "$root/benchmarks/bench_train_sample.py" --train-only --hidden 1024 --batch 2048 --train-precision bf16
+step train1024 200 python3 "$root/benchmarks/bench_train_sample.py" --train-only --hidden 1024 --batch 2048 --train-precision bf16
+step train1024_fp32 200 python3 "$root/benchmarks/bench_train_sample.py" --train-only --hidden 1024 --batch 2048
+step layered_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/layered_stats" -o layered -- python3 "$root/benchmarks/bench_layered.py" --rows 262144 --one-t
+step pmc_layered_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_layered_fetch" -o pmc -- python3 "$root/benchmarks/bench_layered.py" --rows 262144 --one-t
+step pmc_layered_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_layered_write" -o pmc -- python3 "$root/benchmarks/bench_layered.py" --rows 262144 --one-t
+step graph_chain_512 300 python3 "$root/benchmarks/bench_graph.py" --hidden 512 --rows 1024,8192
+step graph_chain_1024 300 python3 "$root/benchmarks/bench_graph.py" --hidden 1024 --rows 1024,8192
+step chain_state 300 python3 "$root/benchmarks/bench_chain.py"
 step kernels_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kernels_stats" -o kernels -- python3 "$root/benchmarks/bench_kernels.py"
 step pmc_kernels_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_kernels_fetch" -o pmc -- python3 "$root/benchmarks/bench_kernels.py" --hbm-only
 step pmc_kernels_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_kernels_write" -o pmc -- python3 "$root/benchmarks/bench_kernels.py" --hbm-only
