@@ -315,6 +315,17 @@ int mtk_train_set_deterministic(mtk_ctx* ctx, int on);
  * distribution and the gradient given the mask (tests feed mtk_train_dropout_mask's masks to the oracle's autograd).  p = 0
  * (default) switches it off; the caller passes a fresh seed per iteration. */
 int mtk_train_set_dropout(mtk_ctx* ctx, double p, uint64_t seed);
+/* MODEL:583-585, 610-612 (IsTargetConditioned.EMBEDDING with num_classes > 0) under training: the denoiser adds
+ * silu(label_embedding.weight[y]) to every record's time embedding, and label_embedding.weight is trained.  Call
+ * mtk_train_set_label_classes(n) after mtk_mlp_set_weights and before mtk_train_image_elems / mtk_train_attach: the training image
+ * gains a layer [n x dim_t] (W = the embedding table, its bias slot unused) placed after the time-embedding MLP - so the order of
+ * the tensors of mtk_train_export / mtk_train_import becomes proj, temb.0, temb.2, label_embedding, blocks..., head - zero until
+ * imported.  mtk_train_set_labels hands over the int64 labels [B] (device memory, caller-owned, read by the next mtk_train_step /
+ * mtk_train_forward / mtk_train_backward); labels outside [0, n) are clamped.  The table's gradient is the scatter of
+ * d act[0] over the labels times silu' (64-bit fixed point, order-independent).  Inference with such a network keeps using
+ * mtk_mlp_set_label_embedding's table rows.  n = 0 (and every mtk_mlp_set_weights) removes the layer. */
+int mtk_train_set_label_classes(mtk_ctx* ctx, int n_labels);
+int mtk_train_set_labels(mtk_ctx* ctx, const int64_t* y_dev);
 /* The keep mask (1 = kept) hidden layer `layer` uses for rows [row0, row0 + B) under the current mtk_train_set_dropout setting:
  * uint8 [B][width of the layer], row-major. */
 int mtk_train_dropout_mask(mtk_ctx* ctx, int layer, int64_t B, uint64_t row0, uint8_t* keep, mtk_stream stream);

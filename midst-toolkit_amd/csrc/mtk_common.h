@@ -67,6 +67,13 @@ struct TrainState {
     // of the iteration's masks
     float drop_p = 0.0f;
     uint64_t drop_seed = 0;
+    // Label-conditioned denoiser under training (MODEL:583-585, 610-612: emb += silu(label_embedding(y))).  The embedding table is a
+    // layer of the training image ([n_label rows][dim_t], no bias in use), added to every record's row of act[0] by the proj
+    // GEMM's epilogue and differentiated by a scatter of d act[0] over the labels (mtk_train_set_label_classes / _set_labels).
+    int n_label = 0;
+    MlpLayer label_l;                // points into the image once attached
+    const int64_t* yvec = nullptr;   // labels of the next iteration's rows (device, caller-owned)
+    long long* dlab_fix = nullptr;   // [label_l.out_pad][emb_ld] fixed-point accumulator, zero between iterations
     int bf16 = 0;  // mtk_train_set_precision: the iteration's GEMMs round their operands to bf16 (fp32 accumulate, fp32 master weights)
     // bf16 mode stores what it multiplies as bf16 (half the bytes through the L2 -> CU pipe that bounds these GEMMs; the values
     // were rounded to bf16 before every product anyway): saved activations, activation gradients, and a copy of the weight

@@ -36,6 +36,7 @@ struct G2 {
     float* C; int64_t c_rs, c_cs;  // C[m * c_rs + n * c_cs]
     const float* bias;             // [grid.y * tile] or null
     const float* emb; int emb_ld;  // optional [T][emb_ld], gathered by tvec[m]
+    const float* lab; const int64_t* yvec; int n_lab, lab_ld;  // with emb, optional: += silu(lab[yvec[m]][n]) (label embedding, MODEL:610-612)
     const int64_t* tvec; int64_t rows_valid; int T;  // per-row timesteps are clamped into [0, T) (mtk_tclamp)
     const float* mask; int64_t m_rs;  // optional row-major activation: result zeroed (times neg_slope) where mask <= 0
     int relu;                      // 1: ReLU / LeakyReLU (neg_slope), 2: SiLU (x / (1 + exp(-x)), the TabSyn denoiser)
@@ -65,6 +66,12 @@ struct G2 {
 
 __device__ __forceinline__ bool g2_keep(uint64_t seed, uint64_t grow, int layer, int n, uint32_t thresh) {
     return mtk_philox((uint32_t)grow, (uint32_t)(grow >> 32), ((uint32_t)layer << 16) | (uint32_t)n, MTK_STREAM_DROP, seed).x >= thresh;
+}
+// silu(label_embedding[y[row]][n]) (MODEL:610-612); rows past the batch read label 0
+__device__ __forceinline__ float g2_label(const float* lab, int lab_ld, int n_lab, const int64_t* yvec, int64_t row, int64_t rows_valid, int n) {
+    const int y = (row < rows_valid) ? mtk_tclamp(yvec[row], n_lab) : 0;
+    const float w = lab[(int64_t)y * lab_ld + n];
+    return w / (1.0f + expf(-w));
 }
 // (scalars, not the argument struct by reference: that put a copy of the struct into scratch memory in the 128-tile kernels)
 __device__ __forceinline__ float g2_dropout(uint32_t thresh, float scale, uint64_t seed, uint64_t grow, int layer, float v, int n) {
@@ -263,6 +270,7 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                 if (g.emb) {
                     const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
                     v += g.emb[(int64_t)tr * g.emb_ld + n];
+                    if (g.lab) v += g2_label(g.lab, g.lab_ld, g.n_lab, g.yvec, row, g.rows_valid, n);
                 }
                 if (g.addend) v += g.addend[row * g.add_rs + n];
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
@@ -478,6 +486,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                     if (g.emb) {
                         const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
                         v += g.emb[(int64_t)tr * g.emb_ld + n];
+                        if (g.lab) v += g2_label(g.lab, g.lab_ld, g.n_lab, g.yvec, row, g.rows_valid, n);
                     }
                     if (g.addend) v += g.addend[row * g.add_rs + n];
                     if (g.relu == 2) v = v / (1.0f + expf(-v));
@@ -524,6 +533,7 @@ __device__ __forceinline__ void gemm2b_finish(const G2& g, f32x16 (&acc)[MT][NT]
                 if (g.emb) {
                     const int tr = (row < g.rows_valid) ? mtk_tclamp(g.tvec[row], g.T) : 0;
                     v += g.emb[(int64_t)tr * g.emb_ld + n];
+                    if (g.lab) v += g2_label(g.lab, g.lab_ld, g.n_lab, g.yvec, row, g.rows_valid, n);
                 }
                 if (g.addend) v += g.addend[row * g.add_rs + n];
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
@@ -877,6 +887,14 @@ __global__ void k_fixed_to_float(long long* acc, float* dst, int64_t n) {
         acc[i] = 0;
     }
 }
+// d label_embedding[y][c] = (sum over the rows labelled y of d act0[row][c]) silu'(label_embedding[y][c]); accumulator left zero
+__global__ void k_label_grad(long long* acc, const float* w, float* dw, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = w[i], sg = 1.0f / (1.0f + expf(-v));
+        dw[i] = (float)((double)acc[i] / kFixScale) * (sg * (1.0f + v * (1.0f - sg)));
+        acc[i] = 0;
+    }
+}
 __global__ void k_silu(const float* z, float* y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = z[i];
@@ -993,6 +1011,7 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
     std::vector<MlpLayer*> v{&c->proj, &c->temb0, &c->temb2};
+    if (c->train.n_label > 0) v.push_back(&c->train.label_l);  // with the time-embedding MLP: same gradient bucket, same point of the backward
     for (auto& l : c->blocks) v.push_back(&l);
     v.push_back(&c->head);
     return v;
@@ -1166,6 +1185,11 @@ void mtk_free_train(mtk_ctx* c) {
     fr(tr.sin_tab); fr(tr.z0_tab); fr(tr.e1_tab); fr(tr.demb); fr(tr.dtab);
     if (tr.demb_fix) (void)hipFree(tr.demb_fix);
     tr.demb_fix = nullptr;
+    if (tr.dlab_fix) (void)hipFree(tr.dlab_fix);
+    tr.dlab_fix = nullptr;
+    tr.yvec = nullptr;
+    tr.n_label = 0;
+    tr.label_l = MlpLayer();
     free_acts(tr);
     if (tr.side) {
         (void)hipStreamSynchronize(tr.side);
@@ -1201,7 +1225,7 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     MTK_HIP(hipSetDevice(c->device));
     MTK_HIP(hipStreamSynchronize(s));
     TrainState& tr = c->train;
-    const size_t n = (size_t)mtk_train_image_elems(c);
+    const size_t n = (size_t)mtk_train_image_elems(c);  // with the label embedding's layer when mtk_train_set_label_classes asked for one (zero until imported)
     tr.layers.clear();
     size_t off = 0;
     for (MlpLayer* l : layer_list(c)) {
@@ -1215,6 +1239,10 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     }
     // image 0 <- current weights; image 4 (EMA) <- the same; gradients, m, v <- 0
     for (auto& r : tr.layers) {
+        if (r.l == &tr.label_l) {
+            MTK_HIP(hipMemsetAsync(state + r.w_off, 0, sizeof(float) * ((size_t)r.l->out_pad * r.l->in_pad + r.l->out_pad), s));
+            continue;
+        }
         MTK_HIP(hipMemcpyAsync(state + r.w_off, r.l->w32, sizeof(float) * (size_t)r.l->out_pad * r.l->in_pad, hipMemcpyDeviceToDevice, s));
         MTK_HIP(hipMemcpyAsync(state + r.b_off, r.l->b32, sizeof(float) * (size_t)r.l->out_pad, hipMemcpyDeviceToDevice, s));
     }
@@ -1243,6 +1271,10 @@ extern "C" int mtk_train_attach(mtk_ctx* c, float* state, const float* freqs_hos
     MTK_HIP(hipMalloc(&tr.dtab, tb));
     MTK_HIP(hipMalloc(&tr.demb_fix, sizeof(long long) * (size_t)tr.Tpad * tp));
     MTK_HIP(hipMemsetAsync(tr.demb_fix, 0, sizeof(long long) * (size_t)tr.Tpad * tp, s));
+    if (tr.n_label > 0) {
+        MTK_HIP(hipMalloc(&tr.dlab_fix, sizeof(long long) * (size_t)tr.label_l.out_pad * tp));
+        MTK_HIP(hipMemsetAsync(tr.dlab_fix, 0, sizeof(long long) * (size_t)tr.label_l.out_pad * tp, s));
+    }
     if (!tr.side) {
         MTK_HIP(hipStreamCreateWithFlags(&tr.side, hipStreamNonBlocking));
         MTK_HIP(hipEventCreateWithFlags(&tr.ev_fork, hipEventDisableTiming));
@@ -1320,6 +1352,10 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.C = const_cast<float*>(act_of(0)); g.c16 = st16; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
         if (st16) { g.Ct = tr.act16t[0]; g.ct_ld = Mpad; }
         g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t; g.rows_valid = B; g.T = c->T;
+        if (tr.n_label > 0) {
+            if (!tr.yvec) MTK_FAIL(MTK_ERR_STATE, "mtk_train_step: the image has a label embedding (mtk_train_set_label_classes): hand over the batch's labels with mtk_train_set_labels first");
+            g.lab = tr.label_l.w32; g.lab_ld = tr.label_l.in_pad; g.n_lab = tr.n_label; g.yvec = tr.yvec;
+        }
         if ((rc = launch<true, false>(g, s))) return rc;
     }
     for (size_t i = 0; i < c->blocks.size(); ++i) {
@@ -1463,6 +1499,13 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
             else hipLaunchKernelGGL(k_scatter_emb<false>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, t, B, c->dim_t, tr.demb, c->emb_ld, c->T);
         }
         const int tp = c->emb_ld;
+        if (tr.n_label > 0) {  // d label_embedding: d act[0] scattered by label (fixed point: order-independent in either reduction mode), times silu'
+            if (!tr.yvec) MTK_FAIL(MTK_ERR_STATE, "mtk_train_backward: no labels (mtk_train_set_labels)");
+            TrainLayerRef& rl = ref_of(&tr.label_l);
+            if (st16) hipLaunchKernelGGL(k_scatter_emb_fixed<true>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, tr.yvec, B, c->dim_t, tr.dlab_fix, tp, tr.n_label);
+            else hipLaunchKernelGGL(k_scatter_emb_fixed<false>, dim3(1024), dim3(64, 4), 0, ss, (const void*)dy, dy_ld, tr.yvec, B, c->dim_t, tr.dlab_fix, tp, tr.n_label);
+            hipLaunchKernelGGL(k_label_grad, dim3(64), dim3(256), 0, ss, tr.dlab_fix, tr.label_l.w32, grads + rl.w_off, (int64_t)tr.label_l.out_pad * tp);
+        }
         MlpLayer &l2 = c->temb2, &l0 = c->temb0;
         TrainLayerRef &r2 = ref_of(&l2), &r0 = ref_of(&l0);
         G2 g{};
@@ -1541,7 +1584,8 @@ extern "C" int mtk_train_bucket_layout(mtk_ctx* c, int max_buckets, int64_t* off
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_bucket_layout: null context");
     if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_bucket_layout: call mtk_train_attach first");
     TrainState& tr = c->train;
-    const int nl = (int)tr.layers.size(), nb = nl - 1;  // temb0 and temb2 share a bucket
+    const int lab = tr.n_label > 0 ? 1 : 0;
+    const int nl = (int)tr.layers.size(), nb = nl - 1 - lab;  // temb0, temb2 (and the label embedding) share a bucket
     if (!off || !len) return nb;
     if (max_buckets < nb) MTK_FAIL(MTK_ERR_ARG, "mtk_train_bucket_layout: %d buckets, room for %d", nb, max_buckets);
     auto span = [&](int first, int last, int b) {
@@ -1549,9 +1593,9 @@ extern "C" int mtk_train_bucket_layout(mtk_ctx* c, int max_buckets, int64_t* off
         len[b] = (int64_t)(tr.layers[last].b_off + tr.layers[last].l->out_pad) - off[b];
     };
     int b = 0;
-    for (int i = nl - 1; i >= 3; --i) span(i, i, b++);  // head, blocks last to first
-    span(0, 0, b++);                                     // proj
-    span(1, 2, b++);                                     // time-embedding MLP
+    for (int i = nl - 1; i >= 3 + lab; --i) span(i, i, b++);  // head, blocks last to first
+    span(0, 0, b++);                                           // proj
+    span(1, 2 + lab, b++);                                     // time-embedding MLP (+ label embedding)
     return nb;
 }
 
@@ -1563,7 +1607,8 @@ extern "C" int mtk_train_set_bucket_events(mtk_ctx* c, int n, void* const* event
         tr.bucket_events.clear();
         return MTK_OK;
     }
-    if (n != (int)tr.layers.size() - 1) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_bucket_events: %d events for %d buckets", n, (int)tr.layers.size() - 1);
+    const int want = (int)tr.layers.size() - 1 - (tr.n_label > 0 ? 1 : 0);
+    if (n != want) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_bucket_events: %d events for %d buckets", n, want);
     tr.bucket_events.assign(n, nullptr);
     for (int i = 0; i < n; ++i) {
         if (!events[i]) {
@@ -1579,6 +1624,28 @@ extern "C" int mtk_train_set_precision(mtk_ctx* c, int precision) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_precision: null context");
     if (precision != MTK_PREC_FP32 && precision != MTK_PREC_BF16) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_set_precision: %d (fp32 or bf16)", precision);
     c->train.bf16 = precision == MTK_PREC_BF16 ? 1 : 0;
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_label_classes(mtk_ctx* c, int n_labels) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_label_classes: null context");
+    if (c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_set_label_classes: call before mtk_train_attach (the image's layout depends on it)");
+    if (n_labels < 0 || n_labels > (1 << 20)) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_label_classes: %d labels", n_labels);
+    if (!c->have_weights) MTK_FAIL(MTK_ERR_STATE, "mtk_train_set_label_classes: call mtk_mlp_set_weights first (it fixes dim_t, and detaching clears the label layer)");
+    TrainState& tr = c->train;
+    tr.n_label = n_labels;
+    tr.label_l = MlpLayer();
+    if (n_labels > 0) {  // rows = labels, columns = dim_t: nn.Embedding's [num_classes, dim_t] weight as a layer's [out][in]
+        tr.label_l.in = c->dim_t; tr.label_l.out = n_labels;
+        tr.label_l.in_pad = c->emb_ld; tr.label_l.out_pad = round_up(n_labels, TN);
+        tr.label_l.owned = false;
+    }
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_labels(mtk_ctx* c, const int64_t* y_dev) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_labels: null context");
+    c->train.yvec = y_dev;
     return MTK_OK;
 }
 

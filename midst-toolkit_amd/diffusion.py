@@ -49,6 +49,17 @@ def _default_device() -> torch.device:
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+def _has_label_table(net) -> bool:
+    return bool(getattr(net, "label_conditioned", False)) and getattr(net, "num_classes", 0) > 0
+
+
+def _image_tensors(net):
+    """(W, b) per layer in the training image's order (a label embedding sits after the time-embedding MLP: trainer._tensors)."""
+    from .trainer import ClavaDDPMTrainer
+
+    return ClavaDDPMTrainer._tensors(net)
+
+
 class _MixedLossFunction(torch.autograd.Function):
     """The autograd seam of ``mixed_loss`` (TRAINER:89-91: ``loss = lm + lg; loss.backward()``): forward is
     mtk_train_forward (noising, denoiser forward with the activations kept on the device context, per-record losses),
@@ -56,8 +67,10 @@ class _MixedLossFunction(torch.autograd.Function):
     fp32 MFMA arithmetic, like ClavaDDPMTrainer's fused iteration (same kernels)."""
 
     @staticmethod
-    def forward(ctx, diffusion, x0, t, eps, u, seed, *params):
+    def forward(ctx, diffusion, x0, t, eps, u, seed, y, *params):
         eng = diffusion._autograd_engine()
+        if y is not None:
+            eng.train_set_labels(y)  # MODEL:610-612: the label-conditioned denoiser's targets (GMD:1042)
         B, dev = x0.shape[0], x0.device
         lm = torch.empty((B,), dtype=torch.float32, device=dev) if eng.C > 0 else None
         lg = torch.empty((B,), dtype=torch.float32, device=dev) if eng.Nn > 0 else None
@@ -80,10 +93,11 @@ class _MixedLossFunction(torch.autograd.Function):
         w_dev = torch.stack([(g_multi if g_multi is not None else zero).to(x0.device, torch.float32).reshape(()),
                              (g_gauss if g_gauss is not None else zero).to(x0.device, torch.float32).reshape(())]) / ctx.B
         ctx.eng.train_backward_dev(ctx.token, x0, t, eps, w_dev.contiguous(), seed=ctx.seed)
-        bufs = [(torch.empty_like(W.data), torch.empty_like(b.data)) for W, b in ctx.net._weights()]
+        bufs = [(torch.empty_like(W.data), torch.empty_like(b.data)) for W, b in _image_tensors(ctx.net)]
         ctx.eng.train_export("grads", bufs)
-        flat = [g for pair in bufs for g in pair]
-        return (None,) * 6 + tuple(g if need else None for g, need in zip(flat, ctx.needs))
+        label = bufs.pop(3)[0] if _has_label_table(ctx.net) else None  # image order: ..., temb.2, label embedding, blocks... (parameters: table last)
+        flat = [g for pair in bufs for g in pair] + ([label] if label is not None else [])
+        return (None,) * 7 + tuple(g if need else None for g, need in zip(flat, ctx.needs))
 
 
 class GaussianMultinomialDiffusion(torch.nn.Module):
@@ -302,10 +316,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         """GMD:1013: (mean multinomial loss / C, mean Gaussian loss).  ``outputs['y']`` reaches the denoiser only when it is
         label-conditioned (MODEL:610); every other denoiser ignores it, as the reference's does."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self._label_net():
-                raise NotImplementedError("label-conditioned denoisers (IsTargetConditioned.EMBEDDING) are forward only on the MI355X path: "
-                                          "score / sample under torch.no_grad(), train with the reference")
-            return self._mixed_loss_autograd(features)
+            y = (outputs or {}).get("y") if self._label_net() else None
+            if self._label_net() and y is None:
+                raise ValueError("mixed_loss: a label-conditioned denoiser needs outputs['y'] (GMD:1042)")
+            return self._mixed_loss_autograd(features, y)
         lm, lg = self.mixed_loss_rows(features, y=(outputs or {}).get("y") if self._label_net() else None)
         return lm.mean(), lg.mean()
 
@@ -319,7 +333,19 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             self.engine()
         eng = self._engine
         key = tuple((p.data_ptr(), p._version) for wb in net._weights() for p in wb)
-        if getattr(eng, "_train_state", None) is None:
+        if _has_label_table(net):
+            key += ((net.label_embedding.weight.data_ptr(), net.label_embedding.weight._version),)
+        if getattr(eng, "_train_state", None) is None and _has_label_table(net):
+            # the diffusion object's context holds no denoiser for such a net (inference runs on the net's own table-row context):
+            # layers, then an image with the label embedding as one more layer, filled from the module
+            freqs = timestep_frequencies(net.timestep_dimension)
+            eng.set_weights(net._weights(), net._dims(), freqs)
+            eng.train_set_label_classes(int(net.num_classes))
+            eng.train_attach(freqs)
+            eng.train_import("weights", _image_tensors(net))
+            eng._image_owner = "autograd"
+            self._ag_key = key
+        elif getattr(eng, "_train_state", None) is None:
             net.sync_weights()  # layer shapes and current weights into the context, then the [5, n] image on top
             eng.train_attach(timestep_frequencies(net.timestep_dimension))
             eng._image_owner = "autograd"
@@ -331,11 +357,11 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
             # importing the stale parameters here would silently reset the run while Adam's moments and the EMA carried on.
             pass
         elif key != getattr(self, "_ag_key", None):  # an optimizer step (or a load) changed the parameters
-            eng.train_import("weights", [(W.data, b.data) for W, b in net._weights()])
+            eng.train_import("weights", _image_tensors(net))
             self._ag_key = key
         return eng
 
-    def _mixed_loss_autograd(self, features: Tensor) -> tuple[Tensor, Tensor]:
+    def _mixed_loss_autograd(self, features: Tensor, y: Tensor | None = None) -> tuple[Tensor, Tensor]:
         """``mixed_loss`` with an autograd graph: ``(lm + lg).backward()`` fills ``param.grad`` of the denoiser's 12 tensors
         from the HIP backward pass, so the reference's own ``ClavaDDPMTrainer`` loop (zero_grad, mixed_loss, backward,
         ``torch.optim.AdamW.step``; TRAINER:70-94) and ``clavaddpm_fine_tuning.py`` run against the drop-in unchanged.
@@ -358,8 +384,9 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         eng = self._autograd_engine()
         eng.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
         eng.train_set_gaussian_loss(getattr(self.gaussian_loss_type, "value", "mse"))  # GMD:534: MSE or the variational-bound term
-        params = [p for wb in net._weights() for p in wb]
-        lm, lg = _MixedLossFunction.apply(self, x0, t, eps, u, seed, *params)
+        params = [p for wb in net._weights() for p in wb] + ([net.label_embedding.weight] if _has_label_table(net) else [])
+        labels = y.to(dev).long().reshape(-1).contiguous() if y is not None else None
+        lm, lg = _MixedLossFunction.apply(self, x0, t, eps, u, seed, labels, *params)
         zero = torch.zeros((1,)).float().mean()  # GMD:1047-1048, 1068: an absent side is the mean of a CPU zeros((1,)), 0-dim
         return (lm if eng.C > 0 else zero), (lg if eng.Nn > 0 else zero)
 

@@ -312,6 +312,18 @@ class Engine:
         """True (default): fixed-order reductions, gradients bit-identical run to run; False: fp32 hardware atomics."""
         check(_lib.lib().mtk_train_set_deterministic(self._h, int(bool(on))))
 
+    def train_set_label_classes(self, n_labels: int) -> None:
+        """A trainable label embedding [n_labels, dim_t] as a layer of the training image (mtk_train_set_label_classes): after
+        set_weights, before train_attach; export / import then carry it after the time-embedding MLP's two layers."""
+        check(_lib.lib().mtk_train_set_label_classes(self._h, int(n_labels)))
+
+    def train_set_labels(self, y: torch.Tensor | None) -> None:
+        """The int64 labels [B] of the next iteration's rows (kept alive here until replaced)."""
+        if y is not None:
+            assert y.dtype == torch.int64 and y.is_contiguous()
+        self._labels = y
+        check(_lib.lib().mtk_train_set_labels(self._h, ptr(y)))
+
     def train_set_dropout(self, p: float, seed: int = 0) -> None:
         """MODEL:162-180 in training mode: hidden activations dropped with probability ``p`` by Philox masks keyed by ``seed``
         (mtk_train_set_dropout); 0 switches it off."""

@@ -55,8 +55,10 @@ class ClavaDDPMTrainer:
         self.seed = 0  # base seed of the in-kernel noise when diffusion_model.rng == "philox"
 
         net = diffusion_model._denoise_fn
-        if getattr(net, "label_conditioned", False):
-            raise NotImplementedError("ClavaDDPMTrainer: label-conditioned denoisers (IsTargetConditioned.EMBEDDING) are forward only on the MI355X path")
+        self._label = bool(getattr(net, "label_conditioned", False))
+        if self._label and getattr(net, "num_classes", 0) == 0:
+            raise NotImplementedError("ClavaDDPMTrainer: IsTargetConditioned.EMBEDDING with num_classes == 0 (a Linear on the raw regression "
+                                      "target, MODEL:587) is not on the MI355X path")
         if getattr(net, "precision", "fp32") != "fp32" or diffusion_model.precision != "fp32":
             raise ValueError("training runs on the fp32 MFMA path: set model.precision = diffusion.precision = 'fp32'")
         self._engine = diffusion_model.engine()
@@ -66,7 +68,16 @@ class ClavaDDPMTrainer:
             self._engine.train_export("weights", self._tensors(net))
             net._synced_key = None
             self._engine = diffusion_model.engine()
+        if self._label:
+            # MODEL:583-585, 610-612.  For inference such a net runs on its own context (label, timestep) table rows; the training
+            # iteration runs on the diffusion object's context, which so far holds no denoiser: give it the layers, then an image
+            # with the label embedding as one more layer, filled from the module
+            self._engine.set_weights(net._weights(), net._dims(), timestep_frequencies(net.timestep_dimension))
+            self._engine.train_set_label_classes(int(net.num_classes))
         self.state = self._engine.train_attach(timestep_frequencies(net.timestep_dimension))
+        if self._label:
+            self._engine.train_import("weights", self._tensors(net))
+            self._engine.train_import("ema", self._tensors(net))
         self._engine._image_owner = "trainer"  # image 0 is the live model from here on: the autograd seam must not overwrite it
         self._engine.train_set_gaussian_loss(getattr(diffusion_model.gaussian_loss_type, "value", "mse"))  # GMD:534
         self._rank, self._world = world()
@@ -103,6 +114,11 @@ class ClavaDDPMTrainer:
             t = torch.randint(0, d.num_timesteps, (B,), device=x0.device).long()
             eps = u = None
             seed = (self.seed + 0x9E3779B97F4A7C15 * (self.optimizer.steps_done + 1)) % (1 << 63)
+        if self._label:  # GMD:1042: the denoiser takes the batch's labels (TRAINER:88 hands mixed_loss the iterator's target dict)
+            y = target.get("y") if isinstance(target, dict) else target
+            if y is None:
+                raise ValueError("ClavaDDPMTrainer: a label-conditioned denoiser needs the batch's labels ({'y': ...})")
+            eng.train_set_labels(y.to(x0.device).long().reshape(-1).contiguous())
         eng.set_math(d.math or ("fast" if (d.rng == "philox" and injected is None) else "reference"))
         p_drop = d._denoise_fn.training_dropout() if hasattr(d._denoise_fn, "training_dropout") else 0.0
         # MODEL:162-180: a fresh mask per iteration, whatever the noise source (its key follows the step count like the Philox noise's)
@@ -157,7 +173,15 @@ class ClavaDDPMTrainer:
     # ------------------------------------------------------------------ state <-> modules
     @staticmethod
     def _tensors(net: nn.Module):
-        return [(W.data, b.data) for W, b in net._weights()]
+        """(W, b) per layer in the training image's order; a label-conditioned net carries its embedding table after the time-embedding
+        MLP's two layers (mtk_train_set_label_classes), with an unused bias slot."""
+        out = [(W.data, b.data) for W, b in net._weights()]
+        if getattr(net, "label_conditioned", False) and getattr(net, "num_classes", 0) > 0:
+            w = net.label_embedding.weight.data
+            if getattr(net, "_label_bias_slot", None) is None or net._label_bias_slot.device != w.device:
+                net._label_bias_slot = torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
+            out.insert(3, (w, net._label_bias_slot))
+        return out
 
     def sync_modules(self) -> None:
         """Write the trained weights into ``diffusion_model._denoise_fn`` and the EMA into ``ema_model``."""
@@ -165,8 +189,11 @@ class ClavaDDPMTrainer:
         self.ema_model.to(self.device)
         self._engine.train_export("weights", self._tensors(net))
         self._engine.train_export("ema", self._tensors(self.ema_model))
-        # the export writes the parameters through raw pointers (no version bump): the EMA copy's own packed image is stale
+        # the export writes the parameters through raw pointers (no version bump): the EMA copy's own packed image is stale, and so
+        # is the table-row context a label-conditioned net keeps for inference
         self.ema_model._synced_key = None
+        if self._label:
+            net._synced_key = None
         torch.cuda.synchronize(self.device)
 
     def set_train_precision(self, precision: str) -> None:

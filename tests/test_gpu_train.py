@@ -300,6 +300,84 @@ def test_trainer_applies_dropout_in_training_mode_only():
             net_train(x0[:8, :].to(dev()), t[:8].to(dev()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_label_conditioned_denoiser_trains(precision):
+    """MODEL:583-585, 610-612 under training (VERDICT r2 missing 1): emb += silu(label_embedding(y)) in the HIP forward, and
+    label_embedding.weight's gradient - d act[0] scattered over the labels, times silu' - beside the other thirteen tensors', all
+    against the oracle's autograd with the same labels (fp32: <= 4e-4 relative L2 - the UNLABELLED net on this batch measures
+    1.2e-4 .. 2.7e-4 per tensor, the loss formulation's conditioning floor at extreme timesteps, and the label path adds nothing
+    to it: a zero table reproduces those figures digit for digit - losses <= 1e-4; bf16 mode: 3e-2, losses 6e-3).  The optimizer step then moves the table, sync_modules writes it back into the module, and the module's own
+    (label, timestep) table-row context evaluates the trained weights."""
+    import midst_toolkit_amd as mtk
+
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[256, 256])
+    n_cls, B = 5, 4096
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    g = torch.Generator().manual_seed(11)
+    p0["label_embedding.weight"] = 0.3 * torch.randn((n_cls, 128), generator=g)
+    x0, t, eps, u = big_batch(c, B)
+    y = torch.randint(0, n_cls, (B, 1), generator=g)
+    s = orc.make_schedule(c["T"], "cosine")
+    want, lm_ref, lg_ref = orc.loss_and_grads(s, c["K"], c["Nn"], p0, x0, t, eps, u, y=y)
+    assert float(want["label_embedding.weight"].norm()) > 0
+    net = mtk.MLPDiffusion(c["D"], n_cls, mtk.IsTargetConditioned.EMBEDDING, mtk.DiffusionParameters(list(c["d_layers"]), 0.0))
+    net.load_state_dict(p0, strict=True)
+    d = mtk.GaussianMultinomialDiffusion(np.asarray(c["K"]), c["Nn"], net, num_timesteps=c["T"], device=dev()).to(dev())
+    tr = mtk.ClavaDDPMTrainer(d, iter(()), 2e-3, 1e-4, 10, device=dev())
+    tr.set_train_precision(precision)
+    lm, lg = tr._train_step(x0, {"y": y}, injected=(t, eps, u))
+    tol_l, tol_g = (1e-4, 4e-4) if precision == "fp32" else (6e-3, 3e-2)  # bf16 on this small net: Gaussian loss off by 4.1e-3 (measured)
+    assert abs(float(lm) - float(lm_ref)) <= tol_l * abs(float(lm_ref)) and abs(float(lg) - float(lg_ref)) <= tol_l * abs(float(lg_ref))
+    bufs = [(torch.empty_like(W), torch.empty_like(b)) for W, b in tr._tensors(net)]
+    tr._engine.train_export("grads", bufs)
+    names = orc.mlp_param_names(len(c["d_layers"]))
+    names.insert(3, "label_embedding")
+    errs = {}
+    for name, (W, b) in zip(names, bufs):
+        pairs = [(name + ".weight", W)] + ([(name + ".bias", b)] if name != "label_embedding" else [])
+        for k, got in pairs:
+            errs[k] = float((got.cpu().double() - want[k].double()).norm()) / max(float(want[k].double().norm()), 1e-30)
+    print("label-conditioned gradients, relative L2 errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= tol_g, errs
+    assert float(bufs[3][1].abs().max()) == 0.0  # the unused bias slot of the embedding's layer stays zero
+    # the step moved the table; the module sees it after sync_modules and serves it through its own inference context
+    before = net.label_embedding.weight.detach().clone()
+    tr.sync_modules()
+    assert not torch.equal(net.label_embedding.weight.detach(), before)
+    trained = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    net.eval()
+    with torch.no_grad():
+        xq = torch.randn((64, c["D"]))
+        tq = torch.randint(0, c["T"], (64,))
+        got = net(xq.to(dev()), tq.to(dev()), y[:64].to(dev()))
+    close(got, orc.mlp_forward(trained, xq, tq, y=y[:64]), rtol=1e-4, atol=1e-5)
+    if precision != "fp32":
+        return
+    # the reference's own loop (zero_grad -> mixed_loss(x, {"y": y}) -> backward -> AdamW.step, TRAINER:70-94) through the autograd seam
+    net2 = mtk.MLPDiffusion(c["D"], n_cls, mtk.IsTargetConditioned.EMBEDDING, mtk.DiffusionParameters(list(c["d_layers"]), 0.0))
+    net2.load_state_dict(p0, strict=True)
+    d2 = mtk.GaussianMultinomialDiffusion(np.asarray(c["K"]), c["Nn"], net2, num_timesteps=c["T"], device=dev()).to(dev())
+    d2._draw_loss_noise = lambda f: (t.to(dev()), eps.to(dev()), u.to(dev()))
+    opt = torch.optim.AdamW(d2.parameters(), lr=1e-3)
+    opt.zero_grad()
+    l_m, l_g = d2.mixed_loss(x0.to(dev()), {"y": y.to(dev())})
+    (l_m + l_g).backward()
+    assert abs(float(l_m.detach()) - float(lm_ref)) <= 1e-4 * abs(float(lm_ref))
+    got = {k: v.grad.detach().cpu() for k, v in net2.named_parameters()}
+    assert set(got) == set(want)
+    for k in want:
+        num, den = float((got[k].double() - want[k].double()).norm()), float(want[k].double().norm())
+        assert num <= 4e-4 * den + 1e-9, f"autograd {k}: relative L2 error {num / max(den, 1e-30):.3e}"
+    w_before = net2.label_embedding.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(net2.label_embedding.weight.detach(), w_before)
+    l_m2, l_g2 = d2.mixed_loss(x0.to(dev()), {"y": y.to(dev())})  # picks the stepped parameters up (image 0 re-imported)
+    assert float(l_m2.detach() + l_g2.detach()) != float(l_m.detach() + l_g.detach())
+    with pytest.raises(ValueError):
+        d2.mixed_loss(x0.to(dev()), {})
+
+
 def test_bf16_training_berka_run():
     """The 200-step Berka run of test_berka_run_200_steps with the bf16 training GEMMs.  Stated tolerance on the loss curve against
     the fp32 reference curve: the first 10 losses within 5e-3, mean deviation <= 4e-2 and max <= 2e-1 over the 200 steps (measured
