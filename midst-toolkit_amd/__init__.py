@@ -6,6 +6,7 @@ from .data import FastTensorDataLoader, endless  # noqa: F401
 from .diffusion import (  # noqa: F401
     FoundNaNsError,
     GaussianLossType,
+    SampleMethod,
     GaussianMultinomialDiffusion,
     GaussianParametrization,
     Parametrization,

@@ -38,6 +38,13 @@ class Parametrization(Enum):
     DIRECT = "direct"
 
 
+class SampleMethod(Enum):
+    """GMD:70."""
+
+    UNIFORM = "uniform"
+    IMPORTANCE = "importance"
+
+
 class FoundNaNsError(BaseException):
     """DU:305."""
 
@@ -261,6 +268,23 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         return cache[key]
 
     # ------------------------------------------------------------------ loss entry point
+    def sample_time(self, batch_size: int, device: torch.device, method: SampleMethod = SampleMethod.UNIFORM) -> tuple[Tensor, Tensor]:
+        """GMD:945-980 (host logic, as in the reference): (timesteps, their probabilities).  UNIFORM is the draw ``mixed_loss`` makes
+        (GMD:1025).  IMPORTANCE weighs timesteps by sqrt(lt_history) once every timestep has more than 10 recorded losses in
+        ``lt_count`` and falls back to UNIFORM until then; nothing in the reference writes those two buffers, so the caller owns
+        their bookkeeping here as there."""
+        method = SampleMethod(getattr(method, "value", method))
+        if method == SampleMethod.IMPORTANCE:
+            if not bool((self.lt_count > 10).all()):
+                return self.sample_time(batch_size, device, method=SampleMethod.UNIFORM)
+            lt_sqrt = torch.sqrt(self.lt_history + 1e-10) + 0.0001
+            lt_sqrt[0] = lt_sqrt[1]  # GMD:967: the decoder term is overwritten with L1
+            pt_all = (lt_sqrt / lt_sqrt.sum()).to(device)
+            timestep = torch.multinomial(pt_all, num_samples=batch_size, replacement=True).to(device)
+            return timestep, pt_all.gather(dim=0, index=timestep)
+        timestep = torch.randint(0, self.num_timesteps, (batch_size,), device=device).long()
+        return timestep, torch.ones_like(timestep).float() / self.num_timesteps
+
     def _draw_loss_noise(self, features: Tensor):
         """The reference's draw order (SURVEY finding 0.5): randint → randn_like → per-column rand_like."""
         B = features.shape[0]

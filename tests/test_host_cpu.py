@@ -208,3 +208,36 @@ def test_integration_snippets_match_the_real_signatures():
     missing = {"AttackFeatureDriver", "drv.add_model", "drv.features", "drv.matrix", "mixed_loss", "ClavaDDPMTrainer"} - seen
     assert not missing, missing
     assert hasattr(distributed, "score_records_sharded") and hasattr(distributed, "sample_all_sharded")  # section 4 names them
+
+
+def test_sample_time_uniform_and_importance():
+    """GMD:945-980 (a3, host logic): UNIFORM = the randint mixed_loss draws, probability 1 / T; IMPORTANCE falls back to UNIFORM until
+    every timestep has more than 10 recorded losses, then draws from sqrt(lt_history) weights (decoder term overwritten with L1)
+    with the same torch calls in the same order as the reference - so a seeded generator gives the reference's timesteps."""
+    import numpy as np
+
+    import midst_toolkit_amd as mtk
+
+    T = 50
+    net = mtk.MLPDiffusion(20, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([64, 64], 0.0))
+    d = mtk.GaussianMultinomialDiffusion(np.asarray([0]), 20, net, num_timesteps=T, device=torch.device("cpu"))
+    cpu = torch.device("cpu")
+    torch.manual_seed(3)
+    t, p = d.sample_time(64, cpu)
+    torch.manual_seed(3)
+    assert torch.equal(t, torch.randint(0, T, (64,)).long()) and torch.equal(p, torch.full((64,), 1.0 / T))
+    torch.manual_seed(3)
+    t2, p2 = d.sample_time(64, cpu, mtk.SampleMethod.IMPORTANCE)   # no history yet: the uniform draw
+    assert torch.equal(t2, t) and torch.equal(p2, p)
+    d.lt_count += 11
+    d.lt_history[:] = torch.linspace(0.0, 4.0, T) ** 2
+    torch.manual_seed(4)
+    t3, p3 = d.sample_time(4096, cpu, "importance")
+    lt = torch.sqrt(d.lt_history + 1e-10) + 0.0001
+    lt[0] = lt[1]
+    w = lt / lt.sum()
+    torch.manual_seed(4)
+    want = torch.multinomial(w, num_samples=4096, replacement=True)
+    assert torch.equal(t3, want) and torch.equal(p3, w.gather(0, want))
+    with pytest.raises(ValueError):
+        d.sample_time(4, cpu, "sobol")
