@@ -1174,7 +1174,10 @@ template <bool FAST> __device__ __forceinline__ float lae_t(float a, float b) {
 // memory passes per block (110 us at any batch size the trainer uses); here wave w takes the categorical blocks
 // k = w, w + kLgWaves, ... and the numeric columns j = w, w + kLgWaves, ... of the same 64 records, and the per-record
 // partial losses meet in LDS, summed in wave order (deterministic).
-constexpr int kLgWaves = 8;
+// Sixteen waves (round 3; eight before): at the trainer's batch sizes the launch is a handful of workgroups whose time is the longest
+// wave's chain, so blocks go to the low waves (k = w) and numeric columns to the high ones (column j to wave kLgWaves - 1 - j mod
+// kLgWaves): with ten blocks and twenty columns no wave carries more than one block plus one column (2,048 rows: 27 -> 17 us).
+constexpr int kLgWaves = 16;
 
 template <bool FAST>
 __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
             const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
             const float* xr = a.x0 + row * a.x0_ld;
             if (!a.kl_tab) {
-                for (int j = w; j < Nn; j += kLgWaves) {
+                for (int j = kLgWaves - 1 - w; j < Nn; j += kLgWaves) {
                     const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
                     const float df = mo[j * a.ld] - e;
                     accg += df * df;
@@ -1212,7 +1215,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 const double lv1 = (double)(float)tb[2], lv2 = tb[3];
                 const double e2 = exp(-lv2), half_head = 0.5 * (((-1.0 + lv2) - lv1) + exp(lv1 - lv2)), inv_stdv = exp(-(0.5 * lv2));
                 const float slope = c1 * st.sqrt_recipm1_acp;  // = -d mean / d eps_hat
-                for (int j = w; j < Nn; j += kLgWaves) {
+                for (int j = kLgWaves - 1 - w; j < Nn; j += kLgWaves) {
                     const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
                     const float xs = xr[j];
                     const float xj = st.sqrt_acp * xs + st.sqrt_1m_acp * e;   // GMD:302, as k_q_sample forms it
