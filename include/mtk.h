@@ -397,7 +397,7 @@ void mtk_clf_destroy(mtk_clf* clf);
 int mtk_clf_guidance(mtk_clf* clf, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,
                      float* logits, float* grad, mtk_stream stream);
 
-/* ---- TabSyn's EDM denoiser, forward only.  Replaces models/tabsyn/model/modules.py:
+/* ---- TabSyn's EDM denoiser.  Replaces models/tabsyn/model/modules.py:
  *   mtk_edm_forward  = MLPDiffusion.forward (modules.py:79-95): out = mlp(proj(x) + time_embed(swap(PositionalEmbedding(labels))))
  *   mtk_edm_denoise  = Preconditioner.forward (modules.py:121-144): c_skip x + c_out F(c_in x, log(sigma) / 4)
  *   mtk_edm_loss     = EDMLoss.__call__ around the Preconditioner (modules.py:165-185) on the caller's draws: rnd_normal [B]
@@ -417,6 +417,18 @@ int mtk_edm_denoise(mtk_edm* edm, int64_t B, const float* x, int64_t x_ld, const
                     float* out, mtk_stream stream);
 int mtk_edm_loss(mtk_edm* edm, int64_t B, const float* y, int64_t y_ld, const float* rnd_normal, const float* noise, double p_mean,
                  double p_std, double sigma_data, float* loss, mtk_stream stream);
+/* EDMLoss under autograd (modules.py:165-185 as the reference's training loop differentiates it, models/tabsyn/pipeline.py's
+ * loss.backward()): mtk_edm_loss_keep is mtk_edm_loss that also keeps, on the handle, every layer's input, the pre-activations of
+ * the four SiLUs and d loss / d F; mtk_edm_backward then turns gout [B, d_in] (= d objective / d loss, g_ld its row stride) into
+ * d objective / d parameters: dW[i] [out, in] and db[i] [out], unpadded device tensors in mtk_edm_create's order.  Hand-written
+ * chain (softmax-free: 2 w (D - y) c_out -> seven weight-gradient GEMMs, five input-gradient GEMMs, SiLU derivatives from the saved
+ * pre-activations) on the fp32 MFMA GEMM of the training iteration; one reduction chunk per GEMM, so gradients are identical
+ * run to run.  One kept forward per handle at a time (B must match).  mtk_edm_set_weights writes new weights of the same
+ * shapes into the handle in place, stream-ordered - an optimizer step does not rebuild the handle. */
+int mtk_edm_loss_keep(mtk_edm* edm, int64_t B, const float* y, int64_t y_ld, const float* rnd_normal, const float* noise, double p_mean,
+                      double p_std, double sigma_data, float* loss, mtk_stream stream);
+int mtk_edm_backward(mtk_edm* edm, int64_t B, const float* gout, int64_t g_ld, float* const* dW, float* const* db, mtk_stream stream);
+int mtk_edm_set_weights(mtk_edm* edm, const float* const* W, const float* const* b, mtk_stream stream);
 
 #ifdef __cplusplus
 }

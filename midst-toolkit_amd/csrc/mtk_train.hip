@@ -42,6 +42,7 @@ struct G2 {
     int relu;                      // 1: ReLU / LeakyReLU (neg_slope), 2: SiLU (x / (1 + exp(-x)), the TabSyn denoiser)
     float neg_slope;               // 0: ReLU; > 0: LeakyReLU slope, forward (relu != 0) and backward (mask != null) alike
     const float* addend; int64_t add_rs;  // optional row-major [M][>= N] matrix added before the activation
+    float* pre; int64_t pre_rs;    // optional (k_gemm2 only): the value before the activation, row-major (SiLU's derivative needs it)
     int atomic;                    // accumulate with fp32 atomic add (split-K)
     float* rowsum;                 // optional [M]: += sum_k A[m][k] (the bias gradient rides in the wgrad GEMM: the waves of
                                    // column tile 0 sum the A fragments they hold anyway; atomics, like C under split-K)
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void k_gemm2(G2 g) {
                     if (g.lab) v += g2_label(g.lab, g.lab_ld, g.n_lab, g.yvec, row, g.rows_valid, n);
                 }
                 if (g.addend) v += g.addend[row * g.add_rs + n];
+                if (g.pre) g.pre[row * g.pre_rs + n] = v;
                 if (g.relu == 2) v = v / (1.0f + expf(-v));
                 else if (g.relu) v = v > 0.0f ? v : g.neg_slope * v;
                 if constexpr (DROP) v = g2_dropout(g.drop_thresh, g.drop_scale, g.drop_seed, g.drop_row0 + (uint64_t)row, g.drop_layer, v, n);
@@ -2061,6 +2063,11 @@ struct mtk_edm {
     int64_t cap = 0;
     float *xin = nullptr, *pe = nullptr, *e1 = nullptr, *emb = nullptr, *h = nullptr, *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *f = nullptr;
     float *sig = nullptr;    // [cap] sigma per record (EDMLoss draws it)
+    // backward of EDMLoss (mtk_edm_loss with keep = 1, then mtk_edm_backward): pre-activations of the four SiLUs, d loss / d F per
+    // unit upstream gradient, gradient ping-pong, padded weight / bias gradients per layer
+    int64_t cap_bwd = 0, kept_rows = 0;
+    float *zt = nullptr, *z0 = nullptr, *z1 = nullptr, *z2 = nullptr, *dfac = nullptr, *dF = nullptr, *d0 = nullptr, *d1 = nullptr;
+    float *gw[7] = {}, *gb[7] = {};
 };
 
 namespace {
@@ -2121,6 +2128,7 @@ struct EdmPost {
     float sigma_data;
     const float* f;
     float* out;
+    float* dfac;  // optional (mode 2): d loss[r][j] / d F[r][j] = 2 w (D - y) c_out, row-major with f's leading dimension
 };
 __global__ __launch_bounds__(256) void k_edm_post(EdmPost a) {
     const int64_t n = a.B * a.d_in;
@@ -2138,13 +2146,40 @@ __global__ __launch_bounds__(256) void k_edm_post(EdmPost a) {
         if (a.mode == 1) { a.out[i] = d; continue; }
         const float w = (sigma * sigma + sd * sd) / ((sigma * sd) * (sigma * sd));
         a.out[i] = w * ((d - y) * (d - y));
+        if (a.dfac) a.dfac[r * a.f_ld + j] = 2.0f * w * (d - y) * c_out;
     }
 }
 
 void edm_free_ws(mtk_edm* e) {
     auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
     fr(e->xin); fr(e->pe); fr(e->e1); fr(e->emb); fr(e->h); fr(e->a0); fr(e->a1); fr(e->a2); fr(e->f); fr(e->sig);
+    fr(e->zt); fr(e->z0); fr(e->z1); fr(e->z2); fr(e->dfac); fr(e->dF); fr(e->d0); fr(e->d1);
     e->cap = 0;
+    e->cap_bwd = 0;
+    e->kept_rows = 0;
+}
+int edm_ensure_bwd(mtk_edm* e, int64_t Mpad, hipStream_t s) {  // after edm_ensure_ws: cap >= Mpad
+    if (Mpad <= e->cap_bwd) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(e->zt); fr(e->z0); fr(e->z1); fr(e->z2); fr(e->dfac); fr(e->dF); fr(e->d0); fr(e->d1);
+    const int64_t rows = e->cap;  // same row capacity as the forward buffers
+    auto al = [&](float*& p, int ld) { return hipMalloc(&p, sizeof(float) * (size_t)rows * ld); };
+    int wide = e->proj.in_pad;
+    for (const MlpLayer* l : {&e->proj, &e->te0, &e->te2, &e->m[0], &e->m[1], &e->m[2], &e->m[3]}) {
+        wide = l->in_pad > wide ? l->in_pad : wide;
+        wide = l->out_pad > wide ? l->out_pad : wide;
+    }
+    MTK_HIP(al(e->zt, e->te0.out_pad)); MTK_HIP(al(e->z0, e->m[0].out_pad)); MTK_HIP(al(e->z1, e->m[1].out_pad)); MTK_HIP(al(e->z2, e->m[2].out_pad));
+    MTK_HIP(al(e->dfac, e->m[3].out_pad)); MTK_HIP(al(e->dF, e->m[3].out_pad)); MTK_HIP(al(e->d0, wide)); MTK_HIP(al(e->d1, wide));
+    MTK_HIP(hipMemsetAsync(e->dfac, 0, sizeof(float) * (size_t)rows * e->m[3].out_pad, s));  // padding of dfac stays zero: k_edm_post writes rows < B, columns < d_in
+    const MlpLayer* ls[7] = {&e->proj, &e->te0, &e->te2, &e->m[0], &e->m[1], &e->m[2], &e->m[3]};
+    for (int i = 0; i < 7; ++i) {
+        if (!e->gw[i]) MTK_HIP(hipMalloc(&e->gw[i], sizeof(float) * (size_t)ls[i]->out_pad * ls[i]->in_pad));
+        if (!e->gb[i]) MTK_HIP(hipMalloc(&e->gb[i], sizeof(float) * (size_t)ls[i]->out_pad));
+    }
+    e->cap_bwd = rows;
+    return MTK_OK;
 }
 int edm_ensure_ws(mtk_edm* e, int64_t Mpad, hipStream_t s) {
     if (Mpad <= e->cap) return MTK_OK;
@@ -2157,34 +2192,38 @@ int edm_ensure_ws(mtk_edm* e, int64_t Mpad, hipStream_t s) {
     e->cap = Mpad;
     return MTK_OK;
 }
-int edm_linear(const MlpLayer& l, int64_t Mpad, const float* in, float* out, int act, const float* addend, int64_t add_rs, hipStream_t s) {
+int edm_linear(const MlpLayer& l, int64_t Mpad, const float* in, float* out, int act, const float* addend, int64_t add_rs, hipStream_t s,
+               float* pre = nullptr) {
     G2 g{};
     g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
     g.A = in; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad; g.C = out; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32;
     g.relu = act; g.addend = addend; g.add_rs = add_rs;
+    g.pre = pre; g.pre_rs = l.out_pad;
     return launch<false, false>(g, s);
 }
 
 // mode: see EdmPre.  lab: labels / sigma / rnd_normal with stride lab_stride.  out: [B][d_in] row-major.
 int edm_run(mtk_edm* e, int mode, int64_t B, const float* x, int64_t x_ld, const float* lab, int64_t lab_stride, const float* noise, double p_mean,
-            double p_std, double sigma_data, float* out, hipStream_t s) {
+            double p_std, double sigma_data, float* out, hipStream_t s, bool keep = false) {
     if (B == 0) return MTK_OK;
     if (B > (1 << 22)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_edm: B = %lld above 4194304 rows per call", (long long)B);
     MTK_HIP(hipSetDevice(e->device));
     const int64_t Mpad = (B + TM - 1) / TM * TM;
     int rc;
     if ((rc = edm_ensure_ws(e, Mpad, s))) return rc;
+    if (keep && (rc = edm_ensure_bwd(e, Mpad, s))) return rc;
+    e->kept_rows = keep ? B : 0;
     EdmPre pa{mode, e->d_in, e->dim_t, e->proj.in_pad, e->te0.in_pad, B, Mpad, x, x_ld, lab, lab_stride, noise, (float)p_mean, (float)p_std,
               (float)sigma_data, e->freqs, e->xin, e->pe, e->sig};
     hipLaunchKernelGGL(k_edm_pre, dim3((unsigned)(Mpad < 4096 ? Mpad : 4096)), dim3(256), 0, s, pa);
-    if ((rc = edm_linear(e->te0, Mpad, e->pe, e->e1, 2, nullptr, 0, s))) return rc;                      // time_embed.0 + SiLU
+    if ((rc = edm_linear(e->te0, Mpad, e->pe, e->e1, 2, nullptr, 0, s, keep ? e->zt : nullptr))) return rc;   // time_embed.0 + SiLU
     if ((rc = edm_linear(e->te2, Mpad, e->e1, e->emb, 0, nullptr, 0, s))) return rc;                     // time_embed.2
     if ((rc = edm_linear(e->proj, Mpad, e->xin, e->h, 0, e->emb, e->te2.out_pad, s))) return rc;         // proj(x) + emb (modules.py:94)
-    if ((rc = edm_linear(e->m[0], Mpad, e->h, e->a0, 2, nullptr, 0, s))) return rc;
-    if ((rc = edm_linear(e->m[1], Mpad, e->a0, e->a1, 2, nullptr, 0, s))) return rc;
-    if ((rc = edm_linear(e->m[2], Mpad, e->a1, e->a2, 2, nullptr, 0, s))) return rc;
+    if ((rc = edm_linear(e->m[0], Mpad, e->h, e->a0, 2, nullptr, 0, s, keep ? e->z0 : nullptr))) return rc;
+    if ((rc = edm_linear(e->m[1], Mpad, e->a0, e->a1, 2, nullptr, 0, s, keep ? e->z1 : nullptr))) return rc;
+    if ((rc = edm_linear(e->m[2], Mpad, e->a1, e->a2, 2, nullptr, 0, s, keep ? e->z2 : nullptr))) return rc;
     if ((rc = edm_linear(e->m[3], Mpad, e->a2, e->f, 0, nullptr, 0, s))) return rc;
-    EdmPost po{mode, e->d_in, e->m[3].out_pad, B, x, x_ld, noise, e->sig, 1, (float)sigma_data, e->f, out};
+    EdmPost po{mode, e->d_in, e->m[3].out_pad, B, x, x_ld, noise, e->sig, 1, (float)sigma_data, e->f, out, (keep && mode == 2) ? e->dfac : nullptr};
     hipLaunchKernelGGL(k_edm_post, dim3(1024), dim3(256), 0, s, po);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -2199,6 +2238,10 @@ extern "C" void mtk_edm_destroy(mtk_edm* e) {
     for (auto& l : e->m) clf_free_layer(l);
     if (e->freqs) (void)hipFree(e->freqs);
     edm_free_ws(e);
+    for (int i = 0; i < 7; ++i) {
+        if (e->gw[i]) (void)hipFree(e->gw[i]);
+        if (e->gb[i]) (void)hipFree(e->gb[i]);
+    }
     delete e;
 }
 
@@ -2252,4 +2295,98 @@ extern "C" int mtk_edm_loss(mtk_edm* e, int64_t B, const float* y, int64_t y_ld,
                             double p_std, double sigma_data, float* loss, mtk_stream stream) {
     if (!e || B < 0 || !y || !rnd_normal || !noise || !loss || y_ld < (e ? e->d_in : 0) || !(sigma_data > 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_loss: bad argument");
     return edm_run(e, 2, B, y, y_ld, rnd_normal, 1, noise, p_mean, p_std, sigma_data, loss, (hipStream_t)stream);
+}
+
+// mtk_edm_loss that keeps what the backward needs on the handle: layer inputs, the pre-activations of the four SiLUs and
+// d loss / d F per unit of upstream gradient.
+extern "C" int mtk_edm_loss_keep(mtk_edm* e, int64_t B, const float* y, int64_t y_ld, const float* rnd_normal, const float* noise, double p_mean,
+                                 double p_std, double sigma_data, float* loss, mtk_stream stream) {
+    if (!e || B <= 0 || !y || !rnd_normal || !noise || !loss || y_ld < (e ? e->d_in : 0) || !(sigma_data > 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_loss_keep: bad argument");
+    return edm_run(e, 2, B, y, y_ld, rnd_normal, 1, noise, p_mean, p_std, sigma_data, loss, (hipStream_t)stream, true);
+}
+
+namespace {
+// dF[r][j] = gout[r][j] * dfac[r][j] for r < B, j < d_in; the padding of the [Mpad][ld] matrix is zero
+__global__ void k_edm_dF(float* dF, const float* dfac, int ld, const float* gout, int64_t g_ld, int64_t B, int d_in, int64_t Mpad) {
+    const int64_t n = Mpad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int j = (int)(i - r * ld);
+        dF[i] = (r < B && j < d_in) ? gout[r * g_ld + j] * dfac[i] : 0.0f;
+    }
+}
+// dW[o][k] = sum_m dy[m][o] in[m][k], db[o] = sum_m dy[m][o] (plain stores: one reduction chunk, run-to-run identical)
+int edm_wgrad(const MlpLayer& l, int64_t Mpad, const float* dy, const float* in, float* dw, float* db, hipStream_t s) {
+    G2 g{};
+    g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; g.kchunk = g.K;
+    g.A = dy; g.lda = l.out_pad; g.B = in; g.ldb = l.in_pad; g.C = dw; g.c_rs = l.in_pad; g.c_cs = 1;
+    g.rowsum_slab = db;
+    return launch<true, true>(g, s);
+}
+// dx[m][k] = sum_o dy[m][o] W[o][k]
+int edm_dgrad(const MlpLayer& l, int64_t Mpad, const float* dy, float* dx, hipStream_t s) {
+    G2 g{};
+    g.M = (int)Mpad; g.N = l.in_pad; g.K = l.out_pad; g.kchunk = g.K;
+    g.A = dy; g.lda = l.out_pad; g.B = l.w32; g.ldb = l.in_pad; g.C = dx; g.c_rs = l.in_pad; g.c_cs = 1;
+    return launch<false, true>(g, s);
+}
+}  // namespace
+
+// EDMLoss backward (modules.py:165-185 under autograd): gout [B][d_in] = d objective / d loss of the last mtk_edm_loss_keep on
+// this handle; dW[i] [out][in] / db[i] [out] (unpadded device tensors, order of mtk_edm_create) receive d objective / d parameters.
+extern "C" int mtk_edm_backward(mtk_edm* e, int64_t B, const float* gout, int64_t g_ld, float* const* dW, float* const* db, mtk_stream stream) {
+    if (!e || !gout || !dW || !db || B <= 0 || g_ld < (e ? e->d_in : 0)) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_backward: bad argument");
+    if (e->kept_rows != B) MTK_FAIL(MTK_ERR_STATE, "mtk_edm_backward: the last mtk_edm_loss_keep on this handle was for %lld rows, not %lld", (long long)e->kept_rows, (long long)B);
+    for (int i = 0; i < 7; ++i)
+        if (!dW[i] || !db[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_backward: dW[%d] or db[%d] is null", i, i);
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(e->device));
+    const int64_t Mpad = (B + TM - 1) / TM * TM;
+    int rc;
+    const int64_t n_el = Mpad;  // rows of every activation matrix
+    auto silu_bwd = [&](const float* z, float* d, int ld) {
+        hipLaunchKernelGGL(k_silu_bwd, dim3(1024), dim3(256), 0, s, z, d, n_el * ld);
+    };
+    hipLaunchKernelGGL(k_edm_dF, dim3(1024), dim3(256), 0, s, e->dF, e->dfac, e->m[3].out_pad, gout, g_ld, B, e->d_in, Mpad);
+    // mlp.6 .. mlp.0 (activations a2, a1, a0, h are the layers' inputs; z2, z1, z0 the pre-activations behind them)
+    if ((rc = edm_wgrad(e->m[3], Mpad, e->dF, e->a2, e->gw[6], e->gb[6], s))) return rc;
+    if ((rc = edm_dgrad(e->m[3], Mpad, e->dF, e->d0, s))) return rc;
+    silu_bwd(e->z2, e->d0, e->m[2].out_pad);
+    if ((rc = edm_wgrad(e->m[2], Mpad, e->d0, e->a1, e->gw[5], e->gb[5], s))) return rc;
+    if ((rc = edm_dgrad(e->m[2], Mpad, e->d0, e->d1, s))) return rc;
+    silu_bwd(e->z1, e->d1, e->m[1].out_pad);
+    if ((rc = edm_wgrad(e->m[1], Mpad, e->d1, e->a0, e->gw[4], e->gb[4], s))) return rc;
+    if ((rc = edm_dgrad(e->m[1], Mpad, e->d1, e->d0, s))) return rc;
+    silu_bwd(e->z0, e->d0, e->m[0].out_pad);
+    if ((rc = edm_wgrad(e->m[0], Mpad, e->d0, e->h, e->gw[3], e->gb[3], s))) return rc;
+    if ((rc = edm_dgrad(e->m[0], Mpad, e->d0, e->d1, s))) return rc;                      // d1 = d h = d emb (modules.py:94: h = proj(x) + emb)
+    if ((rc = edm_wgrad(e->proj, Mpad, e->d1, e->xin, e->gw[0], e->gb[0], s))) return rc;
+    if ((rc = edm_wgrad(e->te2, Mpad, e->d1, e->e1, e->gw[2], e->gb[2], s))) return rc;
+    if ((rc = edm_dgrad(e->te2, Mpad, e->d1, e->d0, s))) return rc;
+    silu_bwd(e->zt, e->d0, e->te0.out_pad);
+    if ((rc = edm_wgrad(e->te0, Mpad, e->d0, e->pe, e->gw[1], e->gb[1], s))) return rc;
+    const MlpLayer* ls[7] = {&e->proj, &e->te0, &e->te2, &e->m[0], &e->m[1], &e->m[2], &e->m[3]};
+    for (int i = 0; i < 7; ++i) {
+        hipLaunchKernelGGL(k_unpad, dim3(256), dim3(256), 0, s, e->gw[i], ls[i]->in_pad, dW[i], ls[i]->out, ls[i]->in);
+        hipLaunchKernelGGL(k_unpad, dim3(4), dim3(256), 0, s, e->gb[i], ls[i]->out_pad, db[i], 1, ls[i]->out);
+    }
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+// New weights into an existing handle (same shapes), in place and stream-ordered: what an optimizer step needs.
+extern "C" int mtk_edm_set_weights(mtk_edm* e, const float* const* W, const float* const* b, mtk_stream stream) {
+    if (!e || !W || !b) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_set_weights: null argument");
+    for (int i = 0; i < 7; ++i)
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_edm_set_weights: W[%d] or b[%d] is null", i, i);
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(e->device));
+    MlpLayer* ls[7] = {&e->proj, &e->te0, &e->te2, &e->m[0], &e->m[1], &e->m[2], &e->m[3]};
+    for (int i = 0; i < 7; ++i) {
+        hipLaunchKernelGGL(k_pad, dim3(256), dim3(256), 0, s, ls[i]->w32, ls[i]->in_pad, W[i], ls[i]->out, ls[i]->in);
+        hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, ls[i]->b32, ls[i]->out_pad, b[i], 1, ls[i]->out);
+    }
+    e->kept_rows = 0;
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
 }

@@ -3,9 +3,11 @@
 reference's constructors and parameter names (a reference state dict loads), and the Euler-Heun ``sample`` / ``sample_step``.
 
 The network forward, the preconditioning and the loss arithmetic run in libmtk_hip.so (``mtk_edm_forward`` / ``mtk_edm_denoise``
-/ ``mtk_edm_loss``: fp32 MFMA GEMMs, fused element-wise kernels either side); nothing goes through torch ops or autograd.
-Forward only: under autograd (training TabSyn's denoiser) the modules raise - train with the reference's module and load the
-result.  There is no CPU path.
+/ ``mtk_edm_loss``: fp32 MFMA GEMMs, fused element-wise kernels either side); nothing goes through torch ops.  Training: the loss
+the reference differentiates - ``Model.forward`` / ``EDMLoss`` (modules.py:165-219) - builds an autograd graph whose backward is
+the library's hand-written chain (``mtk_edm_loss_keep`` / ``mtk_edm_backward``), so ``loss.backward(); optimizer.step()`` of the
+reference's TabSyn loop runs against the drop-in; ``MLPDiffusion.forward`` / ``Preconditioner.forward`` on their own (sampling,
+evaluation) are values, not graphs.  There is no CPU path.
 """
 from __future__ import annotations
 
@@ -63,21 +65,28 @@ class MLPDiffusion(nn.Module):
     def _layers(self):
         return [self.proj, self.time_embed[0], self.time_embed[2], self.mlp[0], self.mlp[2], self.mlp[4], self.mlp[6]]
 
-    def _engine(self, device: torch.device):
-        if any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
-            raise NotImplementedError("the MI355X TabSyn denoiser is forward only: call it under torch.no_grad() (sampling, evaluation); "
-                                      "train with the reference's module and load its state dict")
+    def _engine(self, device: torch.device, differentiable: bool = False):
+        if not differentiable and any(p.requires_grad for p in self.parameters()) and torch.is_grad_enabled():
+            raise NotImplementedError("tabsyn.MLPDiffusion / Preconditioner forward do not build an autograd graph: call them under "
+                                      "torch.no_grad() (sampling, evaluation); the differentiable entry point is the loss (Model / EDMLoss)")
         if device.type != "cuda":
             raise RuntimeError("tabsyn.MLPDiffusion: midst_toolkit_amd has no CPU path; move the module and inputs to the MI355X")
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._handle is not None and key == self._handle_key:
             return self._handle
-        if self._handle is not None:
-            _lib.lib().mtk_edm_destroy(self._handle)
-            self._handle = None
         keep = [(l.weight.detach().float().contiguous().to(device), l.bias.detach().float().contiguous().to(device)) for l in self._layers()]
         Wp = (C.c_void_p * 7)(*[W.data_ptr() for W, _ in keep])
         bp = (C.c_void_p * 7)(*[b.data_ptr() for _, b in keep])
+        if self._handle is not None and self._handle_key is not None and self._handle_key[0] == key[0]:
+            # same device, same shapes (the module's layers are fixed at construction): an optimizer step or a load changed the
+            # values - written into the handle in place (mtk_edm_set_weights), no rebuild
+            with torch.cuda.device(device):
+                check(_lib.lib().mtk_edm_set_weights(self._handle, Wp, bp, _lib.stream_handle(device)))
+            self._handle_key = key
+            return self._handle
+        if self._handle is not None:
+            _lib.lib().mtk_edm_destroy(self._handle)
+            self._handle = None
         fr = np.ascontiguousarray(self.map_noise.frequencies().numpy().astype(np.float32))
         handle = C.c_void_p()
         index = device.index if device.index is not None else torch.cuda.current_device()
@@ -125,6 +134,40 @@ class Preconditioner(nn.Module):
         return out
 
 
+class _EDMLossFunction(torch.autograd.Function):
+    """EDMLoss with a graph: forward = mtk_edm_loss_keep (activations kept on the handle), backward = mtk_edm_backward into
+    fresh gradient tensors for the denoiser's 14 parameters (order of MLPDiffusion._layers)."""
+
+    @staticmethod
+    def forward(ctx, net, y, rnd, n, p_mean, p_std, sigma_data, *params):
+        dev = y.device
+        h = net._engine(dev, differentiable=True)
+        B = y.shape[0]
+        loss = torch.empty((B, net.d_in), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().mtk_edm_loss_keep(h, B, ptr(y), y.stride(0), ptr(rnd), ptr(n), float(p_mean), float(p_std), float(sigma_data),
+                                               ptr(loss), _lib.stream_handle(dev)))
+        net._kept = getattr(net, "_kept", 0) + 1
+        ctx.net, ctx.h, ctx.B, ctx.token = net, h, B, net._kept
+        ctx.needs = [p.requires_grad for p in params]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        if ctx.token != getattr(net, "_kept", None) or ctx.h is not net._handle:
+            raise RuntimeError("backward through a tabsyn loss after another differentiable loss call (or a weight change) on the same "
+                               "model: the handle keeps the activations of one forward pass at a time")
+        g = g.to(torch.float32).contiguous()
+        grads = [(torch.empty_like(l.weight.data, dtype=torch.float32), torch.empty_like(l.bias.data, dtype=torch.float32)) for l in net._layers()]
+        Wp = (C.c_void_p * 7)(*[W.data_ptr() for W, _ in grads])
+        bp = (C.c_void_p * 7)(*[b.data_ptr() for _, b in grads])
+        with torch.cuda.device(g.device):
+            check(_lib.lib().mtk_edm_backward(ctx.h, ctx.B, ptr(g), g.stride(0), Wp, bp, _lib.stream_handle(g.device)))
+        flat = [t for pair in grads for t in pair]
+        return (None,) * 7 + tuple(t if need else None for t, need in zip(flat, ctx.needs))
+
+
 class EDMLoss:
     def __init__(self, p_mean: float = -1.2, p_std: float = 1.2, sigma_data: float = 0.5) -> None:
         self.p_mean, self.p_std, self.sigma_data = p_mean, p_std, sigma_data
@@ -139,7 +182,6 @@ class EDMLoss:
             raise ValueError("EDMLoss and its Preconditioner disagree on sigma_data")
         net = denoise_fn.denoise_model
         dev = data.device
-        h = net._engine(dev)
         y = data.detach().float().contiguous()
         B = y.shape[0]
         if _injected is not None:
@@ -147,6 +189,10 @@ class EDMLoss:
         else:
             rnd = torch.randn(B, device=dev)
             n = torch.randn_like(y)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+            params = [p for l in net._layers() for p in (l.weight, l.bias)]
+            return _EDMLossFunction.apply(net, y, rnd, n, self.p_mean, self.p_std, self.sigma_data, *params)
+        h = net._engine(dev)
         loss = torch.empty((B, net.d_in), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             check(_lib.lib().mtk_edm_loss(h, B, ptr(y), y.stride(0), ptr(rnd), ptr(n), float(self.p_mean), float(self.p_std), float(self.sigma_data),
@@ -162,7 +208,7 @@ class Model(nn.Module):
         self.loss_fn = EDMLoss(p_mean, p_std, sigma_data)
 
     def forward(self, x: Tensor, _injected: tuple[Tensor, Tensor] | None = None) -> Tensor:
-        """modules.py:209-219: the mean loss (a value, not a graph: see the module docstring)."""
+        """modules.py:209-219: the mean loss; with grad enabled and trainable parameters it carries a graph (module docstring)."""
         return self.loss_fn(self.preconditioner, x, _injected).mean(-1).mean()
 
 

@@ -479,6 +479,59 @@ def test_tabsyn_edm_denoiser():
         assert out.shape == (513, 40) and not bool(out.isnan().any())
 
 
+def test_tabsyn_edm_loss_trains():
+    """models/tabsyn/model/modules.py:165-219 under autograd (VERDICT r2 missing 1): Model.forward with grad enabled builds a graph
+    whose backward is the library's chain (mtk_edm_loss_keep / mtk_edm_backward).  On the reference fixture's weights and draws
+    the loss equals the reference's and all fourteen gradient tensors equal the oracle's autograd through the restated modules
+    (<= 3e-4 relative L2 each); gradients are identical run to run; torch.optim.Adam steps on them reduce the loss and the handle
+    takes the new weights in place; a second differentiable forward invalidates the first one's backward."""
+    from midst_toolkit_amd import tabsyn
+    from tests.helpers import load_edm
+
+    c = load_edm()
+    net = tabsyn.MLPDiffusion(c["d_in"], c["dim_t"])
+    net.load_state_dict(c["params"], strict=True)
+    net = net.to(dev())
+    mdl = tabsyn.Model(net)
+    x = tt(c["x"]).to(dev())
+    inj = (tt(c["loss_rnd"]), tt(c["loss_noise"]))
+    p_ref = {k: tt(v).clone().requires_grad_(True) for k, v in c["params"].items()}
+    want = orc.edm_loss(p_ref, tt(c["x"]), inj[0], inj[1], c["dim_t"]).mean(-1).mean()
+    want.backward()
+    loss = mdl(x, inj)
+    assert loss.requires_grad
+    loss.backward()
+    assert abs(float(loss.detach()) - float(c["loss_mean"])) <= RTOL * float(c["loss_mean"])
+    got = {k: v.grad.detach().cpu().clone() for k, v in net.named_parameters()}
+    assert set(got) == set(p_ref)
+    for k, v in p_ref.items():
+        num, den = float((got[k].double() - v.grad.double()).norm()), float(v.grad.double().norm())
+        assert num <= 3e-4 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+    net.zero_grad()
+    mdl(x, inj).backward()
+    assert all(torch.equal(v.grad.cpu(), got[k]) for k, v in net.named_parameters())
+    # the reference's loop: zero_grad -> loss -> backward -> step; same draws every step, so the loss must fall
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    handle = net._handle
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        step_loss = mdl(x, inj)
+        step_loss.backward()
+        opt.step()
+        losses.append(float(step_loss.detach()))
+    assert all(b < a for a, b in zip(losses, losses[1:])) and losses[-1] < 0.95 * losses[0], losses
+    assert net._handle is handle  # new weights went into the same handle
+    with torch.no_grad():
+        assert abs(float(mdl(x, inj)) - losses[-1]) > 0  # evaluation after the last step sees the stepped weights
+    a = mdl(x, inj)
+    b = mdl(x, inj)
+    with pytest.raises(RuntimeError, match="another differentiable"):
+        a.backward()
+    b.backward()
+
+
+
 def test_label_conditioned_denoiser():
     """IsTargetConditioned.EMBEDDING with classes (MODEL:583-585, 610-612) against the reference's own outputs
     (tests/golden/label_label3.npz): the label embedding is extra rows of the time-embedding table
