@@ -397,6 +397,32 @@ void mtk_clf_destroy(mtk_clf* clf);
 int mtk_clf_guidance(mtk_clf* clf, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,
                      float* logits, float* grad, mtk_stream stream);
 
+/* ---- The guidance classifier in TRAINING mode (models/clavaddpm/model.py:45-120 with the module in train(), as
+ * models/clavaddpm/train.py:310-430 and :560-627 drive it: logits = classifier(x_t, timesteps); cross_entropy(...).backward()).
+ * Per hidden stage: Linear -> ReLU (first stage) / LeakyReLU -> BatchNorm1d on BATCH statistics -> Dropout; then the output Linear.
+ * mtk_clft_forward returns the logits and every stage's batch mean / biased batch variance (the caller updates its running
+ * statistics as torch does: momentum 0.1, unbiased variance); mtk_clft_backward turns d objective / d logits into the gradients of
+ * all Linear weights / biases and BatchNorm gamma / beta - the batch-norm backward goes through the batch statistics
+ * (d a = gamma istd / B (B dy - sum dy - xhat sum dy xhat)).  Dropout masks are Philox (counter = row, stage, column; key = seed), as
+ * in mtk_train_set_dropout.  The time embedding is evaluated per record, so its layers get plain weight gradients.  fp32 MFMA
+ * GEMMs; one reduction chunk per GEMM and fixed-order column sums: identical run to run.  The object owns padded copies of the
+ * parameters (mtk_clft_set_params, in place) and the activations of ONE forward (mtk_clft_backward's B must match).
+ * widths_host: n_hidden hidden widths, then n_out; slopes_host [n_hidden]: 0 for ReLU, 0.01 for nn.LeakyReLU();
+ * W / b: n_hidden + 4 tensors in the order proj, timestep_embedding.0, timestep_embedding.2, model's Linear layers. */
+typedef struct mtk_clft mtk_clft;
+int mtk_clft_create(int device, int D_in, int dim_t, int n_hidden, const int32_t* widths_host, const float* slopes_host,
+                    const float* freqs_host, mtk_stream stream, mtk_clft** out);
+void mtk_clft_destroy(mtk_clft* clft);
+int mtk_clft_set_params(mtk_clft* clft, const float* const* W, const float* const* b, const float* const* gamma, const float* const* beta,
+                        mtk_stream stream);
+int mtk_clft_forward(mtk_clft* clft, int64_t B, const float* x, int64_t x_ld, const int64_t* t, double dropout_p, uint64_t seed, double bn_eps,
+                     float* logits, float* const* batch_mean, float* const* batch_var, mtk_stream stream);
+int mtk_clft_backward(mtk_clft* clft, int64_t B, const float* dlogits, int64_t g_ld, float* const* dW, float* const* db, float* const* dgamma,
+                      float* const* dbeta, mtk_stream stream);
+/* The keep mask (1 = kept) Dropout stage `stage` used in the last mtk_clft_forward: uint8 [B][width of the stage] (tests feed it to
+ * the oracle's autograd: torch's own Bernoulli stream cannot be reproduced off-device). */
+int mtk_clft_dropout_mask(mtk_clft* clft, int stage, int64_t B, uint8_t* keep, mtk_stream stream);
+
 /* ---- TabSyn's EDM denoiser.  Replaces models/tabsyn/model/modules.py:
  *   mtk_edm_forward  = MLPDiffusion.forward (modules.py:79-95): out = mlp(proj(x) + time_embed(swap(PositionalEmbedding(labels))))
  *   mtk_edm_denoise  = Preconditioner.forward (modules.py:121-144): c_skip x + c_out F(c_in x, log(sigma) / 4)

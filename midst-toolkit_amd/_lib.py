@@ -81,6 +81,12 @@ _SIGS = {
     "mtk_edm_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, _p, _p]),
     "mtk_edm_denoise": (C.c_int, [_p, _i64, _p, _i64, _p, _i64, C.c_double, _p, _p]),
     "mtk_edm_loss": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, C.c_double, C.c_double, _p, _p]),
+    "mtk_clft_create": (C.c_int, [_i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "mtk_clft_destroy": (None, [_p]),
+    "mtk_clft_set_params": (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    "mtk_clft_forward": (C.c_int, [_p, _i64, _p, _i64, _p, C.c_double, _u64, C.c_double, _p, _p, _p, _p]),
+    "mtk_clft_dropout_mask": (C.c_int, [_p, _i32, _i64, _p, _p]),
+    "mtk_clft_backward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "mtk_edm_loss_keep": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, C.c_double, C.c_double, _p, _p]),
     "mtk_edm_backward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
     "mtk_edm_set_weights": (C.c_int, [_p, _p, _p, _p]),

@@ -2390,3 +2390,369 @@ extern "C" int mtk_edm_set_weights(mtk_edm* e, const float* const* W, const floa
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
+
+
+// =================================================================================================================
+// The guidance classifier under TRAINING (models/clavaddpm/model.py:45-120 in train mode, as train.py:310-430 drives it:
+// logits = classifier(x_t, t); cross_entropy(logits, y).backward(); AdamW.step()).  Per hidden stage
+//     u = Linear(h);  a = ReLU | LeakyReLU(u);  y = BatchNorm1d(a) with BATCH statistics;  h' = Dropout(y)
+// forward and the hand-written backward of exactly that, on the fp32 MFMA GEMM above plus four small column kernels for the
+// batch-norm statistics.  The time embedding is evaluated per record (sinusoid -> Linear -> SiLU -> Linear), as the reference does,
+// so its gradients are plain weight gradients.  Dropout masks are the Philox keep masks of the denoiser's iteration
+// (counter = row, stage, column).  The caller owns parameters, running statistics and the optimizer; this object owns
+// padded copies and the activations of one forward pass.
+// =================================================================================================================
+struct mtk_clft {
+    int device = 0, D_in = 0, dim_t = 0, n_hidden = 0, n_out = 0;
+    std::vector<float> slopes;             // [n_hidden]
+    MlpLayer proj, te0, te2;
+    std::vector<MlpLayer> lin;             // n_hidden + 1 (the last one is the output layer)
+    std::vector<float*> gamma, beta;       // [n_hidden] padded [out_pad]
+    std::vector<float*> mean, istd;        // batch statistics of the last forward, padded
+    std::vector<float*> gw, gb, ggam, gbet, s1, s2;
+    float* freqs = nullptr;
+    int64_t cap = 0, kept_rows = 0;
+    float p_drop = 0.0f, bn_eps = 1e-5f;
+    uint64_t seed = 0;
+    float *xin = nullptr, *pe = nullptr, *zt = nullptr, *e1 = nullptr, *emb = nullptr, *logits = nullptr, *d0 = nullptr, *d1 = nullptr;
+    std::vector<float*> h, a;              // h[i]: input of stage i (h[0] = proj + emb); a[i]: activation output of stage i
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_clft_pre(float* xin, int in_pad, float* pe, int tp, const float* x, int64_t x_ld, const int64_t* t, int64_t B,
+                                                  int64_t Mpad, int D_in, int dim_t, const float* freqs) {
+    const int half = dim_t / 2;
+    for (int64_t r = blockIdx.x; r < Mpad; r += gridDim.x) {
+        for (int j = threadIdx.x; j < in_pad; j += 256) xin[r * in_pad + j] = (r < B && j < D_in) ? x[r * x_ld + j] : 0.0f;
+        const float tv = r < B ? (float)t[r] : 0.0f;
+        for (int j = threadIdx.x; j < tp; j += 256) {  // MODEL:123-144: [cos | sin]
+            float v = 0.0f;
+            if (r < B && j < 2 * half) {
+                const float arg = tv * freqs[j < half ? j : j - half];
+                v = j < half ? cosf(arg) : sinf(arg);
+            }
+            pe[r * tp + j] = v;
+        }
+    }
+}
+// per column of a [B][ld] matrix: mean and 1 / sqrt(biased variance + eps) over the B rows (two passes, rows in a fixed order)
+__global__ __launch_bounds__(256) void k_col_stats(const float* a, int ld, int64_t B, float eps, float* mean, float* istd, float* var_out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float sm = 0.0f;
+    for (int64_t r = g; r < B; r += 4) sm += a[r * ld + c];
+    red[g][threadIdx.x & 63] = sm;
+    __syncthreads();
+    const float mu = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)B;
+    __syncthreads();
+    float sq = 0.0f;
+    for (int64_t r = g; r < B; r += 4) {
+        const float d = a[r * ld + c] - mu;
+        sq += d * d;
+    }
+    red[g][threadIdx.x & 63] = sq;
+    __syncthreads();
+    if (g == 0) {
+        const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)B;
+        mean[c] = mu;
+        istd[c] = 1.0f / sqrtf(var + eps);
+        var_out[c] = var;
+    }
+}
+// h'[r][c] = dropout(gamma xhat + beta), xhat = (a - mean) istd; rows >= B and padding columns (gamma = beta = 0) come out zero
+__global__ void k_bn_fwd(const float* a, float* hn, int ld, int64_t B, int64_t Mpad, const float* mean, const float* istd, const float* gamma,
+                         const float* beta, uint32_t thresh, float scale, uint64_t seed, int stage) {
+    const int64_t n = Mpad * ld;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.0f;
+        if (r < B) {
+            v = gamma[c] * ((a[i] - mean[c]) * istd[c]) + beta[c];
+            if (thresh != 0) v = g2_keep(seed, (uint64_t)r, stage, c, thresh) ? v * scale : 0.0f;
+        }
+        hn[i] = v;
+    }
+}
+// s1[c] = sum_r dy, s2[c] = sum_r dy xhat, dy = dropout'(d h')
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* dh, const float* a, int ld, int64_t B, const float* mean, const float* istd,
+                                                      uint32_t thresh, float scale, uint64_t seed, int stage, float* s1, float* s2) {
+    __shared__ float r1[4][64], r2[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float a1 = 0.0f, a2 = 0.0f;
+    const float mu = mean[c], is = istd[c];
+    for (int64_t r = g; r < B; r += 4) {
+        float dy = dh[r * ld + c];
+        if (thresh != 0) dy = g2_keep(seed, (uint64_t)r, stage, c, thresh) ? dy * scale : 0.0f;
+        a1 += dy;
+        a2 += dy * ((a[r * ld + c] - mu) * is);
+    }
+    r1[g][threadIdx.x & 63] = a1;
+    r2[g][threadIdx.x & 63] = a2;
+    __syncthreads();
+    if (g == 0) {
+        s1[c] = r1[0][threadIdx.x] + r1[1][threadIdx.x] + r1[2][threadIdx.x] + r1[3][threadIdx.x];
+        s2[c] = r2[0][threadIdx.x] + r2[1][threadIdx.x] + r2[2][threadIdx.x] + r2[3][threadIdx.x];
+    }
+}
+// d u = act'(a) gamma istd / B (B dy - s1 - xhat s2)   (batch-norm backward through the batch statistics, then the activation);
+// written over d h' in place; rows >= B zero
+__global__ void k_bn_bwd_apply(float* dh, const float* a, int ld, int64_t B, int64_t Mpad, const float* mean, const float* istd, const float* gamma,
+                               const float* s1, const float* s2, float slope, uint32_t thresh, float scale, uint64_t seed, int stage) {
+    const int64_t n = Mpad * ld;
+    const float invB = 1.0f / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.0f;
+        if (r < B) {
+            float dy = dh[i];
+            if (thresh != 0) dy = g2_keep(seed, (uint64_t)r, stage, c, thresh) ? dy * scale : 0.0f;
+            const float av = a[i], xh = (av - mean[c]) * istd[c];
+            const float da = gamma[c] * istd[c] * invB * ((float)B * dy - s1[c] - xh * s2[c]);
+            v = av > 0.0f ? da : slope * da;
+        }
+        dh[i] = v;
+    }
+}
+__global__ void k_scale_cols(const float* s2, const float* s1, float* dgamma, float* dbeta, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { dgamma[i] = s2[i]; dbeta[i] = s1[i]; }
+}
+
+void clft_free_ws(mtk_clft* c) {
+    auto fr = [](float*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    fr(c->xin); fr(c->pe); fr(c->zt); fr(c->e1); fr(c->emb); fr(c->logits); fr(c->d0); fr(c->d1);
+    for (auto& p : c->h) fr(p);
+    for (auto& p : c->a) fr(p);
+    c->h.clear(); c->a.clear();
+    c->cap = 0; c->kept_rows = 0;
+}
+int clft_ensure_ws(mtk_clft* c, int64_t Mpad, hipStream_t s) {
+    if (Mpad <= c->cap) return MTK_OK;
+    MTK_HIP(hipStreamSynchronize(s));
+    clft_free_ws(c);
+    auto al = [&](float*& p, int ld) { return hipMalloc(&p, sizeof(float) * (size_t)Mpad * ld); };
+    int wide = c->proj.in_pad > c->proj.out_pad ? c->proj.in_pad : c->proj.out_pad;
+    for (auto& l : c->lin) wide = l.out_pad > wide ? l.out_pad : wide;
+    MTK_HIP(al(c->xin, c->proj.in_pad)); MTK_HIP(al(c->pe, c->te0.in_pad)); MTK_HIP(al(c->zt, c->te0.out_pad)); MTK_HIP(al(c->e1, c->te0.out_pad));
+    MTK_HIP(al(c->emb, c->te2.out_pad)); MTK_HIP(al(c->logits, c->lin.back().out_pad)); MTK_HIP(al(c->d0, wide)); MTK_HIP(al(c->d1, wide));
+    c->h.assign(c->n_hidden + 1, nullptr);
+    c->a.assign(c->n_hidden, nullptr);
+    MTK_HIP(al(c->h[0], c->proj.out_pad));
+    for (int i = 0; i < c->n_hidden; ++i) {
+        MTK_HIP(al(c->a[i], c->lin[i].out_pad));
+        MTK_HIP(al(c->h[i + 1], c->lin[i].out_pad));
+    }
+    c->cap = Mpad;
+    return MTK_OK;
+}
+
+}  // namespace
+
+extern "C" void mtk_clft_destroy(mtk_clft* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    clf_free_layer(c->proj); clf_free_layer(c->te0); clf_free_layer(c->te2);
+    for (auto& l : c->lin) clf_free_layer(l);
+    auto frv = [](std::vector<float*>& v) { for (auto& p : v) if (p) (void)hipFree(p); v.clear(); };
+    frv(c->gamma); frv(c->beta); frv(c->mean); frv(c->istd); frv(c->gw); frv(c->gb); frv(c->ggam); frv(c->gbet); frv(c->s1); frv(c->s2);
+    if (c->freqs) (void)hipFree(c->freqs);
+    clft_free_ws(c);
+    delete c;
+}
+
+// widths_host: n_hidden hidden widths then n_out; slopes_host: activation slope of every hidden stage (0 = ReLU, 0.01 = LeakyReLU);
+// W / b: n_hidden + 4 device tensors in the order proj, timestep_embedding.0, timestep_embedding.2, model's Linear layers;
+// gamma / beta: the n_hidden BatchNorm1d affine parameters.
+extern "C" int mtk_clft_create(int device, int D_in, int dim_t, int n_hidden, const int32_t* widths_host, const float* slopes_host,
+                               const float* freqs_host, mtk_stream stream, mtk_clft** out) {
+    if (!out) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_create: out is null");
+    *out = nullptr;
+    if (D_in < 1 || dim_t < 2 || dim_t > 1024 || (dim_t & 1) || n_hidden < 1 || n_hidden > 30 || !widths_host || !slopes_host || !freqs_host)
+        MTK_FAIL(MTK_ERR_ARG, "mtk_clft_create: bad argument");
+    for (int i = 0; i <= n_hidden; ++i)
+        if (widths_host[i] < 1 || widths_host[i] > 8192) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_clft_create: layer width %d", widths_host[i]);
+    int n_dev = 0;
+    MTK_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_create: device %d of %d", device, n_dev);
+    MTK_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    mtk_clft* c = new mtk_clft();
+    c->device = device; c->D_in = D_in; c->dim_t = dim_t; c->n_hidden = n_hidden; c->n_out = widths_host[n_hidden];
+    c->slopes.assign(slopes_host, slopes_host + n_hidden);
+    const int tp = round_up(dim_t, TN);
+    auto shape = [&](MlpLayer& l, int in, int outw, int in_pad) -> int {  // zero-filled padded buffers; values come with mtk_clft_set_params
+        l.in = in; l.out = outw; l.in_pad = in_pad; l.out_pad = round_up(outw, TN);
+        MTK_HIP(hipMalloc(&l.w32, sizeof(float) * (size_t)l.out_pad * l.in_pad));
+        MTK_HIP(hipMalloc(&l.b32, sizeof(float) * (size_t)l.out_pad));
+        MTK_HIP(hipMemsetAsync(l.w32, 0, sizeof(float) * (size_t)l.out_pad * l.in_pad, s));
+        MTK_HIP(hipMemsetAsync(l.b32, 0, sizeof(float) * (size_t)l.out_pad, s));
+        return MTK_OK;
+    };
+    int rc;
+    auto fail = [&](int code) { mtk_clft_destroy(c); return code; };
+    if ((rc = shape(c->proj, D_in, dim_t, round_up(D_in, TN))) || (rc = shape(c->te0, dim_t, dim_t, tp)) || (rc = shape(c->te2, dim_t, dim_t, tp))) return fail(rc);
+    c->lin.resize(n_hidden + 1);
+    int prev = dim_t, prev_pad = tp;
+    for (int i = 0; i <= n_hidden; ++i) {
+        if ((rc = shape(c->lin[i], prev, widths_host[i], prev_pad))) return fail(rc);
+        prev = widths_host[i];
+        prev_pad = c->lin[i].out_pad;
+    }
+    auto alz = [&](std::vector<float*>& v, int i, size_t n) -> int {
+        float* p = nullptr;
+        MTK_HIP(hipMalloc(&p, sizeof(float) * n));
+        MTK_HIP(hipMemsetAsync(p, 0, sizeof(float) * n, s));
+        v[i] = p;
+        return MTK_OK;
+    };
+    for (auto* v : {&c->gamma, &c->beta, &c->mean, &c->istd, &c->ggam, &c->gbet, &c->s1, &c->s2}) v->assign(n_hidden, nullptr);
+    c->gw.assign(n_hidden + 4, nullptr);
+    c->gb.assign(n_hidden + 4, nullptr);
+    for (int i = 0; i < n_hidden; ++i)
+        for (auto* v : {&c->gamma, &c->beta, &c->mean, &c->istd, &c->ggam, &c->gbet, &c->s1, &c->s2})
+            if ((rc = alz(*v, i, (size_t)c->lin[i].out_pad))) return fail(rc);
+    std::vector<MlpLayer*> all{&c->proj, &c->te0, &c->te2};
+    for (auto& l : c->lin) all.push_back(&l);
+    for (size_t i = 0; i < all.size(); ++i)
+        if ((rc = alz(c->gw, (int)i, (size_t)all[i]->out_pad * all[i]->in_pad)) || (rc = alz(c->gb, (int)i, (size_t)all[i]->out_pad))) return fail(rc);
+    hipError_t e = hipMalloc(&c->freqs, sizeof(float) * (dim_t / 2));
+    if (e == hipSuccess) e = hipMemcpyAsync(c->freqs, freqs_host, sizeof(float) * (dim_t / 2), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        mtk_set_error("mtk_clft_create: %s", hipGetErrorString(e));
+        return fail(MTK_ERR_HIP);
+    }
+    *out = c;
+    return MTK_OK;
+}
+
+extern "C" int mtk_clft_set_params(mtk_clft* c, const float* const* W, const float* const* b, const float* const* gamma, const float* const* beta,
+                                   mtk_stream stream) {
+    if (!c || !W || !b || !gamma || !beta) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_set_params: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    std::vector<MlpLayer*> all{&c->proj, &c->te0, &c->te2};
+    for (auto& l : c->lin) all.push_back(&l);
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_set_params: W[%zu] or b[%zu] is null", i, i);
+        hipLaunchKernelGGL(k_pad, dim3(256), dim3(256), 0, s, all[i]->w32, all[i]->in_pad, W[i], all[i]->out, all[i]->in);
+        hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, all[i]->b32, all[i]->out_pad, b[i], 1, all[i]->out);
+    }
+    for (int i = 0; i < c->n_hidden; ++i) {
+        if (!gamma[i] || !beta[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_set_params: gamma[%d] or beta[%d] is null", i, i);
+        hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, c->gamma[i], c->lin[i].out_pad, gamma[i], 1, c->lin[i].out);
+        hipLaunchKernelGGL(k_pad, dim3(4), dim3(256), 0, s, c->beta[i], c->lin[i].out_pad, beta[i], 1, c->lin[i].out);
+    }
+    c->kept_rows = 0;
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+// Training-mode forward: logits [B][n_out] row-major; batch_mean[i] / batch_var[i] (biased) [width_i] of every BatchNorm stage, for the
+// caller's running statistics.  Keeps what mtk_clft_backward needs.  dropout_p in [0, 1), masks keyed by seed.
+extern "C" int mtk_clft_forward(mtk_clft* c, int64_t B, const float* x, int64_t x_ld, const int64_t* t, double dropout_p, uint64_t seed, double bn_eps,
+                                float* logits, float* const* batch_mean, float* const* batch_var, mtk_stream stream) {
+    if (!c || !x || !t || !logits || !batch_mean || !batch_var) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_forward: null argument");
+    if (B < 2) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_forward: batch statistics need at least 2 rows (torch raises on 1 too)");
+    if (B > (1 << 22) || x_ld < c->D_in || !(dropout_p >= 0.0 && dropout_p < 1.0) || !(bn_eps > 0.0)) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_forward: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    const int64_t Mpad = (B + TM - 1) / TM * TM;
+    int rc;
+    if ((rc = clft_ensure_ws(c, Mpad, s))) return rc;
+    c->p_drop = (float)dropout_p; c->seed = seed; c->bn_eps = (float)bn_eps;
+    const double th = dropout_p * 4294967296.0;
+    const uint32_t thresh = dropout_p > 0.0 ? (th >= 4294967295.0 ? 4294967295u : (uint32_t)th) : 0u;
+    const float scale = 1.0f / (1.0f - (float)dropout_p);
+    hipLaunchKernelGGL(k_clft_pre, dim3((unsigned)(Mpad < 4096 ? Mpad : 4096)), dim3(256), 0, s, c->xin, c->proj.in_pad, c->pe, c->te0.in_pad, x, x_ld, t, B,
+                       Mpad, c->D_in, c->dim_t, c->freqs);
+    if ((rc = edm_linear(c->te0, Mpad, c->pe, c->e1, 2, nullptr, 0, s, c->zt))) return rc;          // timestep_embedding.0 + SiLU
+    if ((rc = edm_linear(c->te2, Mpad, c->e1, c->emb, 0, nullptr, 0, s))) return rc;
+    if ((rc = edm_linear(c->proj, Mpad, c->xin, c->h[0], 0, c->emb, c->te2.out_pad, s))) return rc;  // MODEL:118
+    for (int i = 0; i < c->n_hidden; ++i) {
+        const MlpLayer& l = c->lin[i];
+        G2 g{};
+        g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
+        g.A = c->h[i]; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad; g.C = c->a[i]; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32;
+        g.relu = 1; g.neg_slope = c->slopes[i];
+        if ((rc = launch<false, false>(g, s))) return rc;
+        hipLaunchKernelGGL(k_col_stats, dim3(l.out_pad / 64), dim3(256), 0, s, c->a[i], l.out_pad, B, c->bn_eps, c->mean[i], c->istd[i], c->s1[i]);
+        if (!batch_mean[i] || !batch_var[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_forward: batch_mean[%d] or batch_var[%d] is null", i, i);
+        MTK_HIP(hipMemcpyAsync(batch_mean[i], c->mean[i], sizeof(float) * l.out, hipMemcpyDeviceToDevice, s));
+        MTK_HIP(hipMemcpyAsync(batch_var[i], c->s1[i], sizeof(float) * l.out, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_bn_fwd, dim3(1024), dim3(256), 0, s, c->a[i], c->h[i + 1], l.out_pad, B, Mpad, c->mean[i], c->istd[i], c->gamma[i], c->beta[i],
+                           thresh, scale, seed, i);
+    }
+    if ((rc = edm_linear(c->lin.back(), Mpad, c->h[c->n_hidden], c->logits, 0, nullptr, 0, s))) return rc;
+    hipLaunchKernelGGL(k_unpad, dim3(256), dim3(256), 0, s, c->logits, c->lin.back().out_pad, logits, (int)B, c->n_out);
+    MTK_HIP(hipGetLastError());
+    c->kept_rows = B;
+    return MTK_OK;
+}
+
+// dlogits [B][g_ld]: d objective / d logits of the last mtk_clft_forward.  dW / db: n_hidden + 4 unpadded device tensors (order of
+// mtk_clft_set_params); dgamma / dbeta: n_hidden.
+extern "C" int mtk_clft_backward(mtk_clft* c, int64_t B, const float* dlogits, int64_t g_ld, float* const* dW, float* const* db, float* const* dgamma,
+                                 float* const* dbeta, mtk_stream stream) {
+    if (!c || !dlogits || !dW || !db || !dgamma || !dbeta) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_backward: null argument");
+    if (c->kept_rows != B || B <= 0) MTK_FAIL(MTK_ERR_STATE, "mtk_clft_backward: the last mtk_clft_forward on this object was for %lld rows, not %lld", (long long)c->kept_rows, (long long)B);
+    if (g_ld < c->n_out) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_backward: g_ld too small");
+    hipStream_t s = (hipStream_t)stream;
+    MTK_HIP(hipSetDevice(c->device));
+    const int64_t Mpad = (B + TM - 1) / TM * TM;
+    int rc;
+    const double th = (double)c->p_drop * 4294967296.0;
+    const uint32_t thresh = c->p_drop > 0.0f ? (th >= 4294967295.0 ? 4294967295u : (uint32_t)th) : 0u;
+    const float scale = 1.0f / (1.0f - c->p_drop);
+    const int nl = c->n_hidden;
+    // d logits, padded
+    hipLaunchKernelGGL(k_clf_pad_rows, dim3(1024), dim3(256), 0, s, c->d0, c->lin[nl].out_pad, dlogits, g_ld, B, Mpad, c->n_out);
+    float *cur = c->d0, *nxt = c->d1;
+    if ((rc = edm_wgrad(c->lin[nl], Mpad, cur, c->h[nl], c->gw[3 + nl], c->gb[3 + nl], s))) return rc;
+    if ((rc = edm_dgrad(c->lin[nl], Mpad, cur, nxt, s))) return rc;
+    std::swap(cur, nxt);  // cur = d h[nl]
+    for (int i = nl - 1; i >= 0; --i) {
+        const MlpLayer& l = c->lin[i];
+        hipLaunchKernelGGL(k_bn_bwd_stats, dim3(l.out_pad / 64), dim3(256), 0, s, cur, c->a[i], l.out_pad, B, c->mean[i], c->istd[i], thresh, scale, c->seed, i,
+                           c->s1[i], c->s2[i]);
+        hipLaunchKernelGGL(k_scale_cols, dim3(4), dim3(256), 0, s, c->s2[i], c->s1[i], c->ggam[i], c->gbet[i], l.out_pad);
+        hipLaunchKernelGGL(k_bn_bwd_apply, dim3(1024), dim3(256), 0, s, cur, c->a[i], l.out_pad, B, Mpad, c->mean[i], c->istd[i], c->gamma[i], c->s1[i], c->s2[i],
+                           c->slopes[i], thresh, scale, c->seed, i);
+        if ((rc = edm_wgrad(l, Mpad, cur, c->h[i], c->gw[3 + i], c->gb[3 + i], s))) return rc;
+        if ((rc = edm_dgrad(l, Mpad, cur, nxt, s))) return rc;
+        std::swap(cur, nxt);  // cur = d h[i]
+    }
+    // h[0] = proj(x) + emb
+    if ((rc = edm_wgrad(c->proj, Mpad, cur, c->xin, c->gw[0], c->gb[0], s))) return rc;
+    if ((rc = edm_wgrad(c->te2, Mpad, cur, c->e1, c->gw[2], c->gb[2], s))) return rc;
+    if ((rc = edm_dgrad(c->te2, Mpad, cur, nxt, s))) return rc;
+    hipLaunchKernelGGL(k_silu_bwd, dim3(1024), dim3(256), 0, s, c->zt, nxt, Mpad * (int64_t)c->te0.out_pad);
+    if ((rc = edm_wgrad(c->te0, Mpad, nxt, c->pe, c->gw[1], c->gb[1], s))) return rc;
+    std::vector<MlpLayer*> all{&c->proj, &c->te0, &c->te2};
+    for (auto& l : c->lin) all.push_back(&l);
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (!dW[i] || !db[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_backward: dW[%zu] or db[%zu] is null", i, i);
+        hipLaunchKernelGGL(k_unpad, dim3(256), dim3(256), 0, s, c->gw[i], all[i]->in_pad, dW[i], all[i]->out, all[i]->in);
+        hipLaunchKernelGGL(k_unpad, dim3(4), dim3(256), 0, s, c->gb[i], all[i]->out_pad, db[i], 1, all[i]->out);
+    }
+    for (int i = 0; i < nl; ++i) {
+        if (!dgamma[i] || !dbeta[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_backward: dgamma[%d] or dbeta[%d] is null", i, i);
+        hipLaunchKernelGGL(k_unpad, dim3(4), dim3(256), 0, s, c->ggam[i], c->lin[i].out_pad, dgamma[i], 1, c->lin[i].out);
+        hipLaunchKernelGGL(k_unpad, dim3(4), dim3(256), 0, s, c->gbet[i], c->lin[i].out_pad, dbeta[i], 1, c->lin[i].out);
+    }
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
+// The keep mask (1 = kept) Dropout stage `stage` used in the last mtk_clft_forward: uint8 [B][width of the stage], row-major.
+extern "C" int mtk_clft_dropout_mask(mtk_clft* c, int stage, int64_t B, uint8_t* keep, mtk_stream stream) {
+    if (!c || !keep || stage < 0 || stage >= c->n_hidden || B <= 0) MTK_FAIL(MTK_ERR_ARG, "mtk_clft_dropout_mask: bad argument");
+    MTK_HIP(hipSetDevice(c->device));
+    const double th = (double)c->p_drop * 4294967296.0;
+    const uint32_t thresh = c->p_drop > 0.0f ? (th >= 4294967295.0 ? 4294967295u : (uint32_t)th) : 0u;
+    hipLaunchKernelGGL(k_dropout_mask, dim3(1024), dim3(256), 0, (hipStream_t)stream, keep, B, c->lin[stage].out, c->seed, (uint64_t)0, stage, thresh);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}

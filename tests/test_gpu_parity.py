@@ -1667,8 +1667,9 @@ def test_classifier_guidance_on_hip():
     c = load_classifier()
     clf = mtk.Classifier(c["Nn"], c["n_classes"], 128, c["hidden"], dropout_prob=0.1).to(dev())
     clf.load_state_dict(c["state"], strict=True)
-    with pytest.raises(NotImplementedError):
-        clf.train()(torch.zeros((2, c["Nn"]), device=dev()), torch.zeros(2, dtype=torch.long, device=dev()))
+    clf.train()
+    with pytest.raises(NotImplementedError):  # the input gradient is the eval-mode network's (training mode: test_classifier_trains_on_hip)
+        clf.guidance_gradient(torch.zeros((2, c["Nn"]), device=dev()), torch.zeros(2, dtype=torch.long, device=dev()), torch.zeros(2, dtype=torch.long, device=dev()))
     clf.eval()
     x, t, y = tt(c["x"]).to(dev()), tt(c["t"]).to(dev()), tt(c["y"]).to(dev())
     with torch.no_grad():
@@ -1743,3 +1744,98 @@ def test_weight_update_with_unchanged_shapes_allocates_nothing(tag, precision):
     net(x, t)
     assert eng.alloc_count() == n0
     ng.__exit__(None, None, None)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_classifier_trains_on_hip(p_drop):
+    """MODEL:45-120 with the module in train() (VERDICT r2 missing 1; TRAIN:409-425, 560-627: logits = classifier(x_t, t);
+    cross_entropy(logits, y).backward(); AdamW.step()).  The oracle is torch's own modules on the CPU - the reference's
+    Classifier IS this stack of nn.Linear / ReLU / LeakyReLU / BatchNorm1d / Dropout - run in training mode with the library's
+    dropout masks injected (torch's Bernoulli stream cannot be reproduced off-device).  Logits <= 1e-4 of the row scale; every
+    gradient tensor (14 + 2 per BatchNorm) <= 3e-4 relative L2; running_mean / running_var / num_batches_tracked as torch
+    updates them; identical run to run; an AdamW loop on it lowers the loss; eval mode afterwards uses the trained statistics."""
+    import copy
+
+    import torch.nn.functional as F
+    from torch import nn
+
+    import midst_toolkit_amd as mtk
+    from tests.helpers import load_classifier
+
+    c = load_classifier()
+    torch.manual_seed(3)
+    clf = mtk.Classifier(c["Nn"], c["n_classes"], 128, c["hidden"], dropout_prob=p_drop)
+    clf.load_state_dict(c["state"], strict=True)
+    ref = copy.deepcopy(clf)            # stays on the CPU: plain torch modules
+    clf = clf.to(dev())
+    B = 777                             # not a tile multiple
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B, c["Nn"]), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    y = torch.randint(0, c["n_classes"], (B,), generator=g)
+
+    def ref_forward(m, masks):
+        emb = m.timestep_embedding(orc.timestep_embedding(t, 128))
+        h = m.proj(x) + emb
+        k = 0
+        for layer in m.model:
+            if isinstance(layer, nn.Dropout):
+                if m.training and p_drop > 0:
+                    h = h * masks[k].float() / (1 - p_drop)
+                k += 1
+            else:
+                h = layer(h)
+        return h
+
+    clf.train()
+    ref.train()
+    clf.dropout_seed = 99
+    logits = clf(x.to(dev()), t.to(dev()))
+    assert logits.requires_grad
+    masks = [m.cpu() for m in clf.dropout_masks(B)] if p_drop > 0 else None
+    if p_drop > 0:
+        assert all(abs(float(m.float().mean()) - (1 - p_drop)) < 0.02 for m in masks)
+    F.cross_entropy(logits, y.to(dev())).backward()
+    want_logits = ref_forward(ref, masks)
+    F.cross_entropy(want_logits, y).backward()
+    scale = want_logits.detach().abs().amax(dim=1, keepdim=True).clamp_min(1e-3)
+    assert float(((logits.detach().cpu() - want_logits.detach()).abs() / scale).max()) <= 1e-4
+    got = {k: v.grad.detach().cpu() for k, v in clf.named_parameters()}
+    for k, v in ref.named_parameters():
+        if k.startswith("transformer_layer"):
+            continue
+        num, den = float((got[k].double() - v.grad.double()).norm()), float(v.grad.double().norm())
+        assert num <= 3e-4 * den + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e}"
+    for (k, b_got), (_, b_ref) in zip(clf.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(b_got.cpu().double(), b_ref.double(), rtol=1e-5, atol=1e-6), k
+    # same seed, same call count -> same masks, same gradients
+    clf2 = mtk.Classifier(c["Nn"], c["n_classes"], 128, c["hidden"], dropout_prob=p_drop)
+    clf2.load_state_dict(c["state"], strict=True)
+    clf2 = clf2.to(dev()).train()
+    clf2.dropout_seed = 99
+    F.cross_entropy(clf2(x.to(dev()), t.to(dev())), y.to(dev())).backward()
+    assert all(torch.equal(v.grad.cpu(), got[k]) for k, v in clf2.named_parameters())
+    # the reference's loop
+    opt = torch.optim.AdamW(clf.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(10):
+        opt.zero_grad()
+        loss = F.cross_entropy(clf(x.to(dev()), t.to(dev())), y.to(dev()))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
+    # eval mode: the trained parameters and running statistics, against torch's eval-mode modules holding the same state
+    clf.eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in clf.state_dict().items()}, strict=True)
+    ref.eval()
+    with torch.no_grad():
+        e_got = clf(x.to(dev()), t.to(dev())).cpu()
+        e_want = ref_forward(ref, None)
+    es = e_want.abs().amax(dim=1, keepdim=True).clamp_min(1e-3)
+    assert float(((e_got - e_want).abs() / es).max()) <= 1e-4
+    a = clf.train()(x.to(dev()), t.to(dev()))
+    b = clf(x.to(dev()), t.to(dev()))
+    with pytest.raises(RuntimeError, match="another training-mode forward"):
+        a.sum().backward()
+    b.sum().backward()
