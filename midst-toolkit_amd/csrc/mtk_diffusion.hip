@@ -805,6 +805,54 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
     }
 }
 
+// The same draws and stores with one lane per (record, item), item = a numeric column or a categorical block (blockIdx.y): at
+// the trainer's batch sizes a lane-per-record launch is a few dozen waves, each walking its record's Nn + C items as one chain
+// (2,048 records, 20 + 10 items: 18 us); spread over the items the chain is one Philox block and a handful of stores.  A numeric
+// lane forms the whole four-normal Philox block of its column and keeps one value, so the work grows fourfold there: for
+// batches that fill the chip by records alone the lane-per-record kernel stays the better one (mtk_q_sample picks).
+// In-kernel noise or injected eps; injected uniforms (the reference's Gumbel arg-max) stay with the kernels above.
+constexpr int64_t kItemsMaxRows = 16384;
+__global__ __launch_bounds__(kBlock) void k_q_sample_items(QSampleArgs a) {
+    const int Nn = a.d.Nn;
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= a.B) return;
+    const int item = blockIdx.y;
+    const int64_t tv = a.t[row];
+    const float* xr = a.x0 + row * a.x0_ld;
+    const float xv = xr[item];  // the column's value, or the block's code (x_0 = [numeric | codes])
+    const int t = mtk_tclamp(tv, a.d.T);
+    const bool bad_t = tv < 0 || tv >= a.d.T;
+    const float qnan = __builtin_nanf("");
+    const SchedRow sr = a.d.rows[t];
+    float* xo = a.x_in + row * a.xi_rs;
+    if (item < Nn) {
+        PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
+        const float e = a.eps ? a.eps[row * Nn + item] : pn.normal(item);
+        const float xt = sr.sqrt_acp * xv + sr.sqrt_1m_acp * e;
+        xo[item * a.xi_cs] = bad_t ? qnan : xt;
+        return;
+    }
+    const int k = item - Nn;
+    const int o = a.d.off[k], Kk = a.d.off[k + 1] - o;
+    PhiloxW pu(a.seed, a.row0 + row, MTK_STREAM_U);
+    const float acp = fexp(sr.log_acp);
+    const int c0 = (int)(long long)xv;
+    const float pc = fexp(sr.log_1m_acp - a.d.logK[k]);  // (1 - acp) / K
+    const float ph = acp + pc;
+    const float p0 = ph / (ph + (float)(Kk - 1) * pc);
+    const float u1 = pu.uniform(2 * k), u2 = pu.uniform(2 * k + 1);
+    int arg = c0;
+    if (u1 >= p0 && Kk > 1) {
+        int j = (int)(u2 * (float)(Kk - 1));
+        j = j > Kk - 2 ? Kk - 2 : j;
+        arg = j + (j >= c0 ? 1 : 0);
+    }
+    a.xt_idx[(int64_t)k * a.B + row] = arg;
+    float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
+    const float hot_v = bad_t ? qnan : 0.0f, cold_v = bad_t ? qnan : MTK_LOG_TINY;
+    for (int c = 0; c < Kk; ++c) xc[c * a.xi_cs] = (c == arg) ? hot_v : cold_v;
+}
+
 struct TruePost { float lt_c0, lt_ct, w_c0, w_ct, w_cc, w_sum, self; };
 
 template <bool LDS_ROWS, bool STAGE, int KC, bool STREAM>
@@ -1179,11 +1227,19 @@ template <bool FAST> __device__ __forceinline__ float lae_t(float a, float b) {
 // kLgWaves): with ten blocks and twenty columns no wave carries more than one block plus one column (2,048 rows: 27 -> 17 us).
 constexpr int kLgWaves = 16;
 
-template <bool FAST>
+// Column loop of one categorical block.  KC > 0: the block's logits sit in KC registers (blocks of at most KC levels: the six passes
+// below then cost one round trip to memory, not six, and the intermediate gradient never leaves the lane), the loop is unrolled KC
+// times under a predicate; KC = 0: any width, every pass from memory.  (A macro, not a functor over lambdas: arrays captured by
+// reference stayed in scratch memory.)
+#define MTK_LG_COLS(i) _Pragma("unroll (KC > 0 ? KC : 1)") for (int i = 0; i < (KC > 0 ? KC : Kk); ++i) if (KC == 0 || i < Kk)
+#define MTK_LG_COL(i) (KC > 0 ? v[KC > 0 ? (i) : 0] : mc[(i) * ld])
+
+template <bool FAST, int KC, bool KL>
 __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
     const Staged s = stage_tables<false>(a.d);
     __shared__ float part_g[kLgWaves][64], part_m[kLgWaves][64];
     const int Nn = a.d.Nn, C = a.d.C, T = a.d.T;
+    const int64_t ld = a.ld;
     const SchedRow srT = s.rows[T - 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float wdm = a.w_dev ? a.w_dev[0] : 1.0f, wdg = a.w_dev ? a.w_dev[1] : 1.0f;
@@ -1200,12 +1256,12 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
             const SchedRow st = s.rows[t];
             const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
             const float* xr = a.x0 + row * a.x0_ld;
-            if (!a.kl_tab) {
+            if (!KL) {
                 for (int j = kLgWaves - 1 - w; j < Nn; j += kLgWaves) {
                     const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
-                    const float df = mo[j * a.ld] - e;
+                    const float df = mo[j * ld] - e;
                     accg += df * df;
-                    go[j * a.ld] = gscale * df;
+                    go[j * ld] = gscale * df;
                 }
             } else {
                 // _vb_terms_bpd (GMD:431-484) and its derivative with respect to the predicted noise: the model mean is
@@ -1219,7 +1275,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                     const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
                     const float xs = xr[j];
                     const float xj = st.sqrt_acp * xs + st.sqrt_1m_acp * e;   // GMD:302, as k_q_sample forms it
-                    const float x0_hat = st.sqrt_recip_acp * xj - st.sqrt_recipm1_acp * mo[j * a.ld];
+                    const float x0_hat = st.sqrt_recip_acp * xj - st.sqrt_recipm1_acp * mo[j * ld];
                     const float mean = c1 * x0_hat + c2 * xj;
                     double term, grad;
                     if (t != 0) {
@@ -1238,7 +1294,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                         grad = pr > 1e-12 ? -(dpr / pr) * (double)slope : 0.0;  // clamp(min = 1e-12) passes no gradient below it
                     }
                     accg += (float)term;
-                    go[j * a.ld] = kscale * (float)grad;
+                    go[j * ld] = kscale * (float)grad;
                 }
             }
             for (int k = w; k < C; k += kLgWaves) {
@@ -1246,8 +1302,13 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 const float logK = s.logK[k];
                 const int c0 = (int)(long long)xr[Nn + k];
                 const int ct = a.xt_idx[(int64_t)k * a.B + row];
-                const float* mc = mo + (int64_t)(Nn + o) * a.ld;
-                float* gc = go + (int64_t)(Nn + o) * a.ld;
+                const float* mc = mo + (int64_t)(Nn + o) * ld;
+                float* gc = go + (int64_t)(Nn + o) * ld;
+                float v[KC > 0 ? KC : 1], gq[KC > 0 ? KC : 1];
+                if (KC > 0) {
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) v[i] = (i < Kk) ? mc[i * ld] : -INFINITY;
+                }
                 const float cq = st.log_1m_alpha - logK;
                 const float q_hot = lae_t<FAST>(0.0f + st.log_alpha, cq), q_cold = lae_t<FAST>(MTK_LOG_TINY + st.log_alpha, cq);
                 const float ce = s1.log_1m_acp - logK;
@@ -1265,15 +1326,15 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 const float w_c0 = ex<FAST>(lt_c0), w_ct = ex<FAST>(lt_ct), w_cc = ex<FAST>(lt_cc);
                 const float w_sum = w_c0 + (float)n_cc * w_cc + ((c0 != ct) ? w_ct : 0.0f);
                 float mx = -INFINITY;
-                for (int i = 0; i < Kk; ++i) mx = fmaxf(mx, mc[i * a.ld]);
+                MTK_LG_COLS(i) mx = fmaxf(mx, MTK_LG_COL(i));
                 float sum = 0.0f;
-                for (int i = 0; i < Kk; ++i) sum += ex<FAST>(mc[i * a.ld] - mx);
+                MTK_LG_COLS(i) sum += ex<FAST>(MTK_LG_COL(i) - mx);
                 const float lsum = lg<FAST>(sum);
                 const float ev_top = (t == 0) ? -lsum : lae_t<FAST>(-lsum + s1.log_acp, ce);
                 const float m_m = ev_top + q_hot;
                 float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
-                for (int i = 0; i < Kk; ++i) {
-                    const float lsm = (mc[i * a.ld] - mx) - lsum;
+                MTK_LG_COLS(i) {
+                    const float lsm = (MTK_LG_COL(i) - mx) - lsum;
                     const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
                     const float un = ev + ((i == ct) ? q_hot : q_cold);
                     b_m += ex<FAST>(un - m_m);
@@ -1287,10 +1348,10 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 const float p_hot = lae_t<FAST>(0.0f + srT.log_acp, cT), p_cold = lae_t<FAST>(MTK_LOG_TINY + srT.log_acp, cT);
                 const float prior_k = ex<FAST>(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (ex<FAST>(p_cold) * (p_cold + logK));
                 accm += ((t == 0) ? -(un_c0 - lse_m) : (acc_kl + lse_m * w_sum)) * (float)T + prior_k;
-                // gradient: first pass stores g_i and accumulates their sum, second pass projects through the softmax
+                // gradient: first pass keeps g_i and accumulates their sum, second pass projects through the softmax
                 float G = 0.0f;
-                for (int i = 0; i < Kk; ++i) {
-                    const float lsm = (mc[i * a.ld] - mx) - lsum;
+                MTK_LG_COLS(i) {
+                    const float lsm = (MTK_LG_COL(i) - mx) - lsum;
                     const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
                     const float un = ev + ((i == ct) ? q_hot : q_cold);
                     const float p = ex<FAST>(un - lse_m);
@@ -1299,11 +1360,13 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                     const float sl = (t == 0) ? 1.0f : ex<FAST>((lsm + s1.log_acp) - ev);
                     const float gi = gun * sl;
                     G += gi;
-                    gc[i * a.ld] = gi;
+                    if (KC > 0) gq[KC > 0 ? i : 0] = gi;
+                    else gc[i * ld] = gi;
                 }
-                for (int i = 0; i < Kk; ++i) {
-                    const float sm = ex<FAST>((mc[i * a.ld] - mx) - lsum);
-                    gc[i * a.ld] = mscale * (gc[i * a.ld] - sm * G);
+                MTK_LG_COLS(i) {
+                    const float sm = ex<FAST>((MTK_LG_COL(i) - mx) - lsum);
+                    const float gi = KC > 0 ? gq[KC > 0 ? i : 0] : gc[i * ld];
+                    gc[i * ld] = mscale * (gi - sm * G);
                 }
             }
         }
@@ -1314,7 +1377,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
             float g = 0.0f, m = 0.0f;
 #pragma unroll
             for (int i = 0; i < kLgWaves; ++i) { g += part_g[i][lane]; m += part_m[i][lane]; }
-            if (a.loss_gauss && Nn > 0) a.loss_gauss[row] = a.kl_tab ? (g / (float)Nn) * 1.44269504088896340736f : g / (float)Nn;
+            if (a.loss_gauss && Nn > 0) a.loss_gauss[row] = KL ? (g / (float)Nn) * 1.44269504088896340736f : g / (float)Nn;
             if (a.loss_multi && C > 0) a.loss_multi[row] = m / (float)C;
         }
         __syncthreads();
@@ -1468,7 +1531,19 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
     }
     int64_t grid = (B + 63) / 64;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(ctx->fast_math ? k_loss_grad<true> : k_loss_grad<false>, dim3((unsigned)grid), dim3(64 * kLgWaves), lds_bytes(ctx, false), stream, a);
+    // blocks of at most kKCache levels are held in registers (MTK_LG_STREAM: the from-memory loops, the A/B switch)
+    const int ml = max_levels(ctx);
+    const int kc = getenv("MTK_LG_STREAM") ? 0 : (ml <= kKCacheSmall ? kKCacheSmall : (ml <= kKCache ? kKCache : 0));
+    const bool kl = a.kl_tab != nullptr;
+    void (*kern)(LossGradArgs);
+    if (ctx->fast_math) {
+        if (kl) kern = kc == kKCacheSmall ? k_loss_grad<true, kKCacheSmall, true> : (kc == kKCache ? k_loss_grad<true, kKCache, true> : k_loss_grad<true, 0, true>);
+        else kern = kc == kKCacheSmall ? k_loss_grad<true, kKCacheSmall, false> : (kc == kKCache ? k_loss_grad<true, kKCache, false> : k_loss_grad<true, 0, false>);
+    } else {
+        if (kl) kern = kc == kKCacheSmall ? k_loss_grad<false, kKCacheSmall, true> : (kc == kKCache ? k_loss_grad<false, kKCache, true> : k_loss_grad<false, 0, true>);
+        else kern = kc == kKCacheSmall ? k_loss_grad<false, kKCacheSmall, false> : (kc == kKCache ? k_loss_grad<false, kKCache, false> : k_loss_grad<false, 0, false>);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kLgWaves), lds_bytes(ctx, false), stream, a);
     MTK_HIP(hipGetLastError());
     return MTK_OK;
 }
@@ -1488,6 +1563,14 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
     // fast math: stage the row-major records through LDS when they are narrow and 16-byte aligned (the slab
     // replaces the LDS copy of the schedule rows, which then come from L2: measured equal)
     const bool stage = ctx->fast_math && x0_ld <= kStageLd && (reinterpret_cast<uintptr_t>(x0) & 15) == 0 && !getenv("MTK_NO_STAGE");
+    // training-sized batches: one lane per (record, item); MTK_QS_ROWS keeps the lane-per-record kernels (the A/B switch of
+    // tests/test_gpu_train.py, which checks that the two give the same bits)
+    if (ctx->fast_math && !u && B <= kItemsMaxRows && ctx->Nn + ctx->C > 0 && ctx->Nn + ctx->C <= 65535 && !getenv("MTK_QS_ROWS")) {
+        hipLaunchKernelGGL(k_q_sample_items, dim3((unsigned)((B + kBlock - 1) / kBlock), (unsigned)(ctx->Nn + ctx->C)), dim3(kBlock), 0,
+                           (hipStream_t)stream, a);
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
+    }
     if (stage) {
         hipLaunchKernelGGL((k_q_sample_fast<false, true>), dim3(grid_for(B, 16384)), dim3(kBlock),
                            lds_bytes(ctx, false) + (size_t)kBlock * x0_ld * sizeof(float), (hipStream_t)stream, a);

@@ -424,6 +424,45 @@ def test_gradients_are_bit_identical_run_to_run(B, layers):
     assert rel < 1e-5, rel  # same sums, another order
 
 
+@pytest.mark.parametrize("K,layers", [([10] * 10, [256, 128, 256]), ([3, 12, 16, 2], [128, 128]), ([4, 30, 7], [128, 128])])
+def test_training_sized_kernels_equal_the_general_ones(monkeypatch, K, layers):
+    """Round 3: at the trainer's batch sizes q_sample runs one lane per (record, item) (k_q_sample_items) and the loss-gradient
+    kernel keeps a block's logits in registers (k_loss_grad<KC>).  Both are re-arrangements, not other arithmetic: under the A/B
+    switches MTK_QS_ROWS / MTK_LG_STREAM (the lane-per-record and from-memory forms, which the parity tests above pinned to the
+    oracle) every output is the same bit for bit - noised rows, drawn codes, per-record losses, the whole gradient image; rows
+    with a timestep outside [0, T) included.  Blocks of 12 and 16 levels sit on the register variants' edges, 30 is streamed."""
+    Nn = 5
+    c = dict(K=K, Nn=Nn, T=1000, D=Nn + sum(K), d_layers=layers)
+    B = 1337
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    x0, t, eps, _ = [v.to(dev()) for v in big_batch(c, B)]
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    eng.set_math("fast")
+    tb = t.clone()
+    tb[7], tb[900] = -1, c["T"]
+    ld = 1408
+
+    def noised(e):
+        x_in = torch.zeros((c["D"], ld), device=dev())
+        idx = torch.zeros((len(K), B), dtype=torch.int32, device=dev())
+        eng.q_sample(x0, tb, e, None, x_in, (1, ld), idx, seed=77, row0=4096)
+        return x_in.view(torch.int32).clone(), idx
+
+    def iteration(e):
+        rows = torch.empty((2, B), device=dev())
+        eng.train_step(x0, t, e, None, 1.0 / B, rows[0], rows[1], seed=77, row0=4096)
+        return rows.clone(), tr.state[1].clone()
+
+    new = [noised(None), noised(eps), iteration(None), iteration(eps)]
+    monkeypatch.setenv("MTK_QS_ROWS", "1")
+    monkeypatch.setenv("MTK_LG_STREAM", "1")
+    old = [noised(None), noised(eps), iteration(None), iteration(eps)]
+    for a, b in zip(new, old):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert bool(torch.isfinite(new[2][0]).all()) and float(new[2][1].abs().sum()) > 0
+
+
 def test_adamw_ema_kernel():
     c = load_train("B_ragged")
     p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
