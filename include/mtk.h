@@ -302,6 +302,17 @@ int mtk_train_attach(mtk_ctx* ctx, float* state, const float* freqs_host, mtk_st
 int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
                    const float* u, double inv_global_batch, float* loss_multi, float* loss_gauss, uint64_t seed,
                    uint64_t row0, mtk_stream stream);
+/* The two remaining per-iteration device launches a host framework would add around mtk_train_step, folded in (no reference
+ * counterpart as entry points; the operations are TRAINER:88 -> GMD:1011 sample_time(UNIFORM) and GMD:1066-1068 the batch means):
+ *  - mtk_train_step / mtk_train_forward with t = NULL draw the timesteps in the noising kernel, uniform over [0, T)
+ *    (Philox-4x32-10 stream 6, word 0 of record row0 + row, scaled by T >> 32: like the in-kernel noise, not torch's stream);
+ *    the backward phase of such a forward takes t = NULL too, and mtk_train_timesteps copies the B drawn values out (int64,
+ *    device) - what a loss-aware sampler's history update (GMD:1062) reads.
+ *  - mtk_train_set_loss_means(ctx, means): every later forward phase that is given loss_multi / loss_gauss also writes their
+ *    batch means to means[0] / means[1] (device floats, caller-owned, 0 for an absent vector; fp64 sums added in a fixed order,
+ *    one workgroup on the iteration's side stream).  NULL (default) switches it off. */
+int mtk_train_set_loss_means(mtk_ctx* ctx, float* means_dev);
+int mtk_train_timesteps(mtk_ctx* ctx, int64_t B, int64_t* t_dev, mtk_stream stream);
 /* No reference counterpart beyond the reference pipeline's torch.use_deterministic_algorithms (common/random.py:11-55): on
  * (default) = the split-batch reductions of the weight gradients are added in a fixed order (partial tiles in slabs) and the
  * time-embedding scatter accumulates in 64-bit fixed point, so gradients are bit-identical run to run; off = fp32 hardware

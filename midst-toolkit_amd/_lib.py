@@ -68,6 +68,8 @@ _SIGS = {
     "mtk_train_set_dropout": (C.c_int, [_p, C.c_double, _u64]),
     "mtk_train_set_label_classes": (C.c_int, [_p, _i32]),
     "mtk_train_set_labels": (C.c_int, [_p, _p]),
+    "mtk_train_set_loss_means": (C.c_int, [_p, _p]),
+    "mtk_train_timesteps": (C.c_int, [_p, C.c_int64, _p, _p]),
     "mtk_train_dropout_mask": (C.c_int, [_p, _i32, _i64, _u64, _p, _p]),
     "mtk_train_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),
     "mtk_train_backward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, C.c_double, _u64, _u64, _p]),

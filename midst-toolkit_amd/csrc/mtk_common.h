@@ -98,6 +98,9 @@ struct TrainState {
     int64_t xin_rows = 0, dout_rows = 0;
     float* xin = nullptr;          // [round_up(D,128)][cap] column-major model input
     int32_t* xt_idx = nullptr;     // [C][cap]
+    int64_t* tdraw = nullptr;      // [cap] timesteps drawn by the library (mtk_train_step with t = null)
+    bool t_drawn = false;          // the last forward phase drew its timesteps (mtk_train_timesteps may copy them out)
+    float* loss_means = nullptr;   // caller's [2] device buffer for the batch means of the two losses (mtk_train_set_loss_means)
     std::vector<float*> act;       // act[0] = proj output, act[i] = block i output, row-major [cap][out_pad]
     float *out = nullptr, *dout = nullptr;  // column-major [Dpad128][cap]
     std::vector<float*> dact;      // dact[i] = d loss / d act[i], row-major [cap][width of act[i]] (one per layer: the weight
@@ -211,6 +214,9 @@ template <typename T> inline int mtk_alloc_t(mtk_ctx* c, T** p, size_t bytes) { 
 // [0, T) with NaN (mtk_poison_bad_t, mtk_diffusion.hip): an out-of-range timestep is loud, never an out-of-bounds read.
 // The reference's sinusoid embedding accepts any t; here the embedding is a [T] table.
 int mtk_ensure_kl_tab(mtk_ctx* ctx);
+// mtk_q_sample with the timesteps drawn in the kernel when t_out is given (written there for the kernels that follow; t is not read)
+int mtk_q_sample_t(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u, float* x_in,
+                   int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed, uint64_t row0, int64_t* t_out, hipStream_t stream);
 int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0, int64_t cs0, int n0, float* p1, int64_t rs1,
                      int64_t cs1, int n1, double* p2, hipStream_t s);
 
@@ -253,7 +259,7 @@ __device__ __forceinline__ uint32_t mtk_pick4(uint32_t a, uint32_t b, uint32_t c
 __device__ __forceinline__ float mtk_pick4f(float a, float b, float c, float d, int j) {
     return __uint_as_float(mtk_pick4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d), j));
 }
-enum { MTK_STREAM_EPS = 1, MTK_STREAM_U = 2, MTK_STREAM_Z0 = 3, MTK_STREAM_U0 = 4, MTK_STREAM_DROP = 5, MTK_STREAM_STEP = 16 };
+enum { MTK_STREAM_EPS = 1, MTK_STREAM_U = 2, MTK_STREAM_Z0 = 3, MTK_STREAM_U0 = 4, MTK_STREAM_DROP = 5, MTK_STREAM_T = 6, MTK_STREAM_STEP = 16 };
 // element j of the normal stream for `row`
 __device__ __forceinline__ float mtk_philox_normal(uint64_t seed, uint64_t row, uint32_t stream, int j) {
     const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(j >> 2), stream, seed);
@@ -264,5 +270,11 @@ __device__ __forceinline__ float mtk_philox_normal(uint64_t seed, uint64_t row, 
 __device__ __forceinline__ float mtk_philox_uniform(uint64_t seed, uint64_t row, uint32_t stream, int j) {
     const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(j >> 2), stream, seed);
     return mtk_u01(mtk_pick4(r.x, r.y, r.z, r.w, j));
+}
+// the record's timestep when the library draws it (mtk_train_step with t = null; the uniform sample_time of GMD:945-953): the
+// first word of the record's MTK_STREAM_T block scaled to [0, T)
+__device__ __forceinline__ int64_t mtk_draw_t(uint64_t seed, uint64_t row, int T) {
+    const uint4 r = mtk_philox((uint32_t)row, (uint32_t)(row >> 32), 0u, MTK_STREAM_T, seed);
+    return (int64_t)(((uint64_t)r.x * (uint64_t)(uint32_t)T) >> 32);
 }
 #endif

@@ -132,6 +132,7 @@ struct QSampleArgs {
     float* x_in; int64_t xi_rs, xi_cs;
     int32_t* xt_idx;
     uint64_t seed, row0;
+    int64_t* t_out;  // non-null: the timestep is drawn here (mtk_draw_t) and written for the kernels that follow; t is not read
 };
 
 template <bool LDS_ROWS>
@@ -139,7 +140,9 @@ __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
     const Staged s = stage_tables<LDS_ROWS>(a.d);
     const int Nn = a.d.Nn, C = a.d.C, S = a.d.S;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.B; row += (int64_t)gridDim.x * kBlock) {
-        const int t = mtk_tclamp(a.t[row], a.d.T);
+        const int64_t tv = a.t_out ? mtk_draw_t(a.seed, a.row0 + row, a.d.T) : a.t[row];
+        if (a.t_out) a.t_out[row] = tv;
+        const int t = mtk_tclamp(tv, a.d.T);
         const SchedRow sr = s.rows[t];
         const float* xr = a.x0 + row * a.x0_ld;
         float* xo = a.x_in + row * a.xi_rs;
@@ -717,7 +720,8 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
             xr = a.x0 + row * a.x0_ld;
         }
         if (row >= a.B) continue;
-        const int64_t tv = a.t[row];
+        const int64_t tv = a.t_out ? mtk_draw_t(a.seed, a.row0 + row, a.d.T) : a.t[row];
+        if (a.t_out) a.t_out[row] = tv;
         const int t = mtk_tclamp(tv, a.d.T);
         // a timestep outside [0, T): the record's outputs are NaN (mtk_tclamp keeps the addressing in bounds); folded into
         // the stores here, so this path needs no k_poison_bad_t pass behind it (a launch and its gap per call)
@@ -817,7 +821,8 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_items(QSampleArgs a) {
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= a.B) return;
     const int item = blockIdx.y;
-    const int64_t tv = a.t[row];
+    const int64_t tv = a.t_out ? mtk_draw_t(a.seed, a.row0 + row, a.d.T) : a.t[row];
+    if (a.t_out && item == 0) a.t_out[row] = tv;
     const float* xr = a.x0 + row * a.x0_ld;
     const float xv = xr[item];  // the column's value, or the block's code (x_0 = [numeric | codes])
     const int t = mtk_tclamp(tv, a.d.T);
@@ -1231,7 +1236,7 @@ constexpr int kLgWaves = 16;
 // below then cost one round trip to memory, not six, and the intermediate gradient never leaves the lane), the loop is unrolled KC
 // times under a predicate; KC = 0: any width, every pass from memory.  (A macro, not a functor over lambdas: arrays captured by
 // reference stayed in scratch memory.)
-#define MTK_LG_COLS(i) _Pragma("unroll (KC > 0 ? KC : 1)") for (int i = 0; i < (KC > 0 ? KC : Kk); ++i) if (KC == 0 || i < Kk)
+#define MTK_LG_COLS(i) _Pragma("clang loop unroll_count(KC > 0 ? KC : 1)") for (int i = 0; i < (KC > 0 ? KC : Kk); ++i) if (KC == 0 || i < Kk)
 #define MTK_LG_COL(i) (KC > 0 ? v[KC > 0 ? (i) : 0] : mc[(i) * ld])
 
 template <bool FAST, int KC, bool KL>
@@ -1551,14 +1556,20 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
 extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps,
                             const float* u, float* x_in, int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed,
                             uint64_t row0, mtk_stream stream) {
+    if (ctx && B > 0 && !t) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
+    return mtk_q_sample_t(ctx, B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0, nullptr, (hipStream_t)stream);
+}
+
+int mtk_q_sample_t(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u, float* x_in,
+                   int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed, uint64_t row0, int64_t* t_out, hipStream_t stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null context");
     if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
-    if (B < 0 || !x0 || !t || !x_in) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
+    if (B < 0 || !x0 || (!t && !t_out) || !x_in) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
     if (ctx->C > 0 && !xt_idx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: xt_idx is required when C > 0");
     if (x0_ld < ctx->Nn + ctx->C) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: x0_ld %lld < Nn + C = %d", (long long)x0_ld, ctx->Nn + ctx->C);
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
-    QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0};
+    QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0, t_out};
     const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
     // fast math: stage the row-major records through LDS when they are narrow and 16-byte aligned (the slab
     // replaces the LDS copy of the schedule rows, which then come from L2: measured equal)
@@ -1580,7 +1591,7 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
     auto k = ctx->fast_math ? (lds ? k_q_sample_fast<true, false> : k_q_sample_fast<false, false>) : (lds ? k_q_sample<true> : k_q_sample<false>);
     hipLaunchKernelGGL(k, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, lds), (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
-    if (ctx->fast_math) return MTK_OK;
+    if (ctx->fast_math || t_out) return MTK_OK;  // drawn timesteps are in range
     return mtk_poison_bad_t(t, B, ctx->T, x_in, xi_rs, xi_cs, ctx->D, nullptr, 0, 0, 0, nullptr, (hipStream_t)stream);
 }
 

@@ -897,6 +897,30 @@ __global__ void k_label_grad(long long* acc, const float* w, float* dw, int64_t 
         acc[i] = 0;
     }
 }
+// means[0] = mean of lm[0..B), means[1] = mean of lg[0..B) (0 for a null vector): one workgroup, fp64 partial sums per thread over a
+// fixed stride, added through LDS in a fixed order (run-to-run identical)
+__global__ __launch_bounds__(1024) void k_loss_means(const float* lm, const float* lg, int64_t B, float* means) {
+    __shared__ double sh[2][1024];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < B; i += 1024) {
+        if (lm) a += (double)lm[i];
+        if (lg) b += (double)lg[i];
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        means[0] = (float)(sh[0][0] / (double)B);
+        means[1] = (float)(sh[1][0] / (double)B);
+    }
+}
 __global__ void k_silu(const float* z, float* y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = z[i];
@@ -1021,7 +1045,8 @@ std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
 
 void free_acts(TrainState& tr) {
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(tr.xin); fr(tr.xt_idx); fr(tr.out); fr(tr.dout); fr(tr.slab); fr(tr.slab_rs);
+    fr(tr.xin); fr(tr.xt_idx); fr(tr.tdraw); fr(tr.out); fr(tr.dout); fr(tr.slab); fr(tr.slab_rs);
+    tr.t_drawn = false;
     for (auto& p : tr.dact) fr(p);
     tr.dact.clear();
     tr.slab_elems = tr.slab_rs_elems = 0;
@@ -1056,6 +1081,7 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     for (auto& l : c->blocks) maxpad = l.out_pad > maxpad ? l.out_pad : maxpad;
     MTK_HIP(hipMalloc(&tr.xin, sizeof(float) * (size_t)Dp * Mpad));
     MTK_HIP(hipMalloc(&tr.xt_idx, sizeof(int32_t) * (size_t)(c->C > 0 ? c->C : 1) * Mpad));
+    MTK_HIP(hipMalloc(&tr.tdraw, sizeof(int64_t) * (size_t)Mpad));
     MTK_HIP(hipMalloc(&tr.out, sizeof(float) * (size_t)Dp * Mpad));
     MTK_HIP(hipMalloc(&tr.dout, sizeof(float) * (size_t)Dp * Mpad));
     MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * Mpad, s));
@@ -1190,6 +1216,7 @@ void mtk_free_train(mtk_ctx* c) {
     if (tr.dlab_fix) (void)hipFree(tr.dlab_fix);
     tr.dlab_fix = nullptr;
     tr.yvec = nullptr;
+    tr.loss_means = nullptr;
     tr.n_label = 0;
     tr.label_l = MlpLayer();
     free_acts(tr);
@@ -1304,7 +1331,10 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
                         bool do_fwd, bool do_bwd, mtk_stream stream, const float* w_dev = nullptr) {
     if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null context");
     if (!c->train.attached) MTK_FAIL(MTK_ERR_STATE, "mtk_train_step: call mtk_train_attach first");
-    if (B <= 0 || !x0 || !t) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null pointer or B <= 0");
+    if (B <= 0 || !x0) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: null pointer or B <= 0");
+    // t = null: the forward phase draws the timesteps itself (uniform over [0, T), Philox: mtk_draw_t) and keeps them for the
+    // backward phase and for mtk_train_timesteps
+    if (!t && !do_fwd && !c->train.t_drawn) MTK_FAIL(MTK_ERR_ARG, "mtk_train_backward: t is null and the last forward phase did not draw its timesteps");
     if (B > (1 << 22)) MTK_FAIL(MTK_ERR_UNSUPPORTED, "mtk_train_step: B = %lld above 4194304 rows per call", (long long)B);
     if (x0_ld < c->Nn + c->C) MTK_FAIL(MTK_ERR_ARG, "mtk_train_step: x0_ld too small");
     hipStream_t s = (hipStream_t)stream;
@@ -1345,7 +1375,9 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
 
     // ---- forward, activations kept
     // xt_idx is addressed [C][B] by the kernels (row stride B)
-    if ((rc = mtk_q_sample(c, B, x0, x0_ld, t, eps, u, tr.xin, 1, ld, tr.xt_idx, seed, row0, stream))) return rc;
+    if ((rc = mtk_q_sample_t(c, B, x0, x0_ld, t, eps, u, tr.xin, 1, ld, tr.xt_idx, seed, row0, t ? nullptr : tr.tdraw, s))) return rc;
+    tr.t_drawn = !t;
+    if (!t) t = tr.tdraw;
     {
         G2 g{};
         g.bf16 = tr.bf16;
@@ -1386,9 +1418,17 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         if ((rc = launch<false, false>(g, s))) return rc;
     }
     }
+    if (!t) t = tr.tdraw;  // backward phase of a forward that drew them
+    auto means = [&](hipStream_t q) {  // batch means of the two per-record loss vectors, for the caller that asked (mtk_train_set_loss_means)
+        if (tr.loss_means && (loss_multi || loss_gauss))
+            hipLaunchKernelGGL(k_loss_means, dim3(1), dim3(1024), 0, q, (const float*)loss_multi, (const float*)loss_gauss, B, tr.loss_means);
+    };
     if (!do_bwd) {  // losses only (the gradient scratch it also fills is rewritten by the backward phase)
         if (B > tr.dout_rows) tr.dout_rows = B;
-        return mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout, 0.0, 0.0, nullptr, seed, row0, s);
+        if ((rc = mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout, 0.0, 0.0, nullptr, seed, row0, s))) return rc;
+        means(s);
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
     }
     // deterministic mode stores every element of the gradient image (the split-batch partials are summed into it, the head
     // bias row sums cover its padding) and of d emb; the atomic mode accumulates into both
@@ -1489,6 +1529,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         MTK_HIP(hipStreamWaitEvent(ss, tr.ev_fork, 0));
     }
     {   // side stream: d emb table = scatter of d act[0] by timestep, then the time-embedding MLP over the T-row table
+        means(ss);  // off the main stream's chain: a one-workgroup reduction nothing in the iteration waits for
         const float* dy = dact_of(0);  // [Mpad][proj.out_pad]
         const int64_t dy_ld = c->proj.out_pad;
         if (tr.deterministic) {
@@ -1619,6 +1660,22 @@ extern "C" int mtk_train_set_bucket_events(mtk_ctx* c, int n, void* const* event
         }
         tr.bucket_events[i] = (hipEvent_t)events[i];
     }
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_loss_means(mtk_ctx* c, float* means_dev) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_loss_means: null context");
+    c->train.loss_means = means_dev;  // null: off
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_timesteps(mtk_ctx* c, int64_t B, int64_t* t_dev, mtk_stream stream) {
+    if (!c || !t_dev) MTK_FAIL(MTK_ERR_ARG, "mtk_train_timesteps: null pointer");
+    TrainState& tr = c->train;
+    if (!tr.attached || !tr.t_drawn || !tr.tdraw) MTK_FAIL(MTK_ERR_STATE, "mtk_train_timesteps: the last forward phase on this context did not draw its timesteps (t = null)");
+    if (B != tr.fwd_rows) MTK_FAIL(MTK_ERR_ARG, "mtk_train_timesteps: %lld rows, the last forward phase had %lld", (long long)B, (long long)tr.fwd_rows);
+    MTK_HIP(hipSetDevice(c->device));
+    MTK_HIP(hipMemcpyAsync(t_dev, tr.tdraw, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MTK_OK;
 }
 

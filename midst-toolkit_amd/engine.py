@@ -263,7 +263,7 @@ class Engine:
 
     def train_step(self, x0, t, eps, u, inv_global_batch, loss_multi=None, loss_gauss=None, seed=0, row0=0) -> None:
         B = x0.shape[0]
-        assert x0.dtype == torch.float32 and x0.stride(1) == 1 and t.dtype == torch.int64 and t.is_contiguous()
+        assert x0.dtype == torch.float32 and x0.stride(1) == 1 and (t is None or (t.dtype == torch.int64 and t.is_contiguous()))
         with torch.cuda.device(self.device):
             check(_lib.lib().mtk_train_step(self._h, B, ptr(x0), x0.stride(0), ptr(t), ptr(eps), ptr(u), float(inv_global_batch),
                                             ptr(loss_multi), ptr(loss_gauss), seed, row0, self._stream()))
@@ -323,6 +323,21 @@ class Engine:
             assert y.dtype == torch.int64 and y.is_contiguous()
         self._labels = y
         check(_lib.lib().mtk_train_set_labels(self._h, ptr(y)))
+
+    def train_set_loss_means(self, means: torch.Tensor | None) -> None:
+        """``means`` (2 fp32 on the device, kept alive here until replaced): later iterations also write the batch means of their
+        two per-record loss vectors there (mtk_train_set_loss_means); None switches it off."""
+        if means is not None:
+            assert means.dtype == torch.float32 and means.is_contiguous() and means.numel() == 2
+        self._loss_means = means
+        check(_lib.lib().mtk_train_set_loss_means(self._h, ptr(means)))
+
+    def train_timesteps(self, B: int) -> torch.Tensor:
+        """The timesteps the last iteration drew itself (train_step with ``t=None``; mtk_train_timesteps)."""
+        t = torch.empty((B,), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_timesteps(self._h, B, ptr(t), self._stream()))
+        return t
 
     def train_set_dropout(self, p: float, seed: int = 0) -> None:
         """MODEL:162-180 in training mode: hidden activations dropped with probability ``p`` by Philox masks keyed by ``seed``

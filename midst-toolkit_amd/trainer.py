@@ -111,8 +111,9 @@ class ClavaDDPMTrainer:
         elif d.rng == "torch":
             t, eps, u = d._draw_loss_noise(x0)
         else:
-            t = torch.randint(0, d.num_timesteps, (B,), device=x0.device).long()
-            eps = u = None
+            # the library draws the timesteps with the noise (uniform over [0, T): GMD:1011 sample_time(UNIFORM)) and takes the two
+            # batch means on the iteration's side stream: no launch of the host framework is left in the iteration
+            t = eps = u = None
             seed = (self.seed + 0x9E3779B97F4A7C15 * (self.optimizer.steps_done + 1)) % (1 << 63)
         if self._label:  # GMD:1042: the denoiser takes the batch's labels (TRAINER:88 hands mixed_loss the iterator's target dict)
             y = target.get("y") if isinstance(target, dict) else target
@@ -123,25 +124,24 @@ class ClavaDDPMTrainer:
         p_drop = d._denoise_fn.training_dropout() if hasattr(d._denoise_fn, "training_dropout") else 0.0
         # MODEL:162-180: a fresh mask per iteration, whatever the noise source (its key follows the step count like the Philox noise's)
         eng.train_set_dropout(p_drop, (self.seed + 0xD1B54A32D192ED03 * (self.optimizer.steps_done + 1)) % (1 << 63) if p_drop else 0)
-        t = t.to(x0.device, torch.int64).contiguous()
+        t = t.to(x0.device, torch.int64).contiguous() if t is not None else None
         eps = eps.to(x0.device).float().contiguous() if eps is not None and eps.numel() else None
         u = u.to(x0.device).float().contiguous() if u is not None and u.numel() else None
-        # both per-row loss vectors in one buffer: their batch means are one reduction launch, not two plus a fill for the absent one
+        # per-record losses (one buffer for both) and their batch means, the latter taken by the library inside the iteration
         rows = torch.empty((2, B), dtype=torch.float32, device=x0.device) if (eng.C > 0 and eng.Nn > 0) else None
         lm = rows[0] if rows is not None else (torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.C > 0 else None)
         lg = rows[1] if rows is not None else (torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None)
+        means = torch.empty((2,), dtype=torch.float32, device=x0.device)  # a fresh pair per iteration: the caller may keep what is returned
+        eng.train_set_loss_means(means)
         eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
+        eng.train_set_loss_means(None)
         if self._exchange is not None:  # the one exchange of an iteration, bucket by bucket under the backward
             self._exchange.launch()
             self._exchange.wait()
         g = self.optimizer.param_groups[0]
         self.optimizer.steps_done += 1
         eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
-        if rows is not None:
-            means = rows.mean(dim=1)
-            return means[0], means[1]
-        zero = torch.zeros((), dtype=torch.float32, device=x0.device)
-        return (lm.mean() if lm is not None else zero), (lg.mean() if lg is not None else zero)
+        return means[0], means[1]
 
     # ------------------------------------------------------------------ TRAINER:96
     def train(self) -> None:

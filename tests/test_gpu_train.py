@@ -463,6 +463,53 @@ def test_training_sized_kernels_equal_the_general_ones(monkeypatch, K, layers):
     assert bool(torch.isfinite(new[2][0]).all()) and float(new[2][1].abs().sum()) > 0
 
 
+def test_library_draws_the_timesteps_and_takes_the_batch_means():
+    """Round 3: with rng = "philox" the trainer hands the iteration no timesteps (mtk_train_step, t = NULL: GMD:1011's uniform
+    sample_time drawn in the noising kernel) and reads the two batch means from the library (mtk_train_set_loss_means) - no torch
+    launch is left in the iteration.  Checked: the drawn t are in range, uniform (chi-square over 20 bins), differ between seeds
+    and between ranks' row offsets; an iteration given those t explicitly reproduces losses and gradients bit for bit in both
+    math modes; the means equal the fp64 means of the per-record losses; the trainer's returned pair is that."""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[256, 128, 256])
+    B = 6000
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    x0 = big_batch(c, B)[0].to(dev())
+    tr, d = build_trainer(c, p0)
+    eng = tr._engine
+    means = torch.full((2,), -1.0, device=dev())
+    eng.train_set_loss_means(means)
+    for math in ("fast", "reference"):
+        eng.set_math(math)
+        rows = torch.empty((2, B), device=dev())
+        eng.train_step(x0, None, None, None, 1.0 / B, rows[0], rows[1], seed=11, row0=B)
+        got_means, grads, t = means.clone(), tr.state[1].clone(), eng.train_timesteps(B)
+        assert int(t.min()) >= 0 and int(t.max()) < c["T"]
+        counts = torch.bincount(t // 50, minlength=20).double().cpu()
+        assert float(((counts - B / 20) ** 2 / (B / 20)).sum()) < 50.0  # 19 degrees of freedom: 1e-4 tail at 49
+        ref = rows.double().mean(dim=1)
+        assert float((got_means.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+        rows2 = torch.empty((2, B), device=dev())
+        eng.train_step(x0, t, None, None, 1.0 / B, rows2[0], rows2[1], seed=11, row0=B)
+        assert torch.equal(rows, rows2) and torch.equal(grads, tr.state[1]) and torch.equal(means, got_means)
+        if math == "fast":
+            t_fast = t
+    assert torch.equal(t, t_fast)  # the draw does not depend on the math mode
+    eng.train_step(x0, None, None, None, 1.0 / B, rows[0], rows[1], seed=12, row0=B)
+    assert not torch.equal(eng.train_timesteps(B), t)
+    eng.train_step(x0, None, None, None, 1.0 / B, rows[0], rows[1], seed=11, row0=0)
+    assert not torch.equal(eng.train_timesteps(B), t)
+    eng.train_set_loss_means(None)
+    with pytest.raises(RuntimeError):
+        eng.train_step(x0, t, None, None, 1.0 / B, None, None, seed=11)
+        eng.train_timesteps(B)  # the last forward was given its timesteps
+    # the trainer: nothing but the library's launches, the returned pair is the means of that iteration
+    d.rng = "philox"
+    lm, lg = tr._train_step(x0)
+    assert lm.shape == () and bool(torch.isfinite(lm)) and bool(torch.isfinite(lg)) and float(lg) > 0 and float(lm) > 0
+    keep = (float(lm), float(lg))
+    tr._train_step(x0)
+    assert (float(lm), float(lg)) == keep  # a fresh pair per iteration: what was returned earlier is not overwritten
+
+
 def test_adamw_ema_kernel():
     c = load_train("B_ragged")
     p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
