@@ -97,6 +97,8 @@ struct TrainState {
     // allocated, the kernels write rows < B only, and a call with fewer rows than the last one zeroes them again first
     int64_t xin_rows = 0, dout_rows = 0;
     float* xin = nullptr;          // [round_up(D,128)][cap] column-major model input
+    uint16_t *xin16 = nullptr, *dout16 = nullptr;  // bf16 copies of xin / dout, same layout and zero padding: in bf16 mode the noising and
+                                   // loss-gradient kernels write them too, and the proj / head weight gradients read those (LDS-DMA GEMM)
     int32_t* xt_idx = nullptr;     // [C][cap]
     int64_t* tdraw = nullptr;      // [cap] timesteps drawn by the library (mtk_train_step with t = null)
     bool t_drawn = false;          // the last forward phase drew its timesteps (mtk_train_timesteps may copy them out)
@@ -215,8 +217,9 @@ template <typename T> inline int mtk_alloc_t(mtk_ctx* c, T** p, size_t bytes) { 
 // The reference's sinusoid embedding accepts any t; here the embedding is a [T] table.
 int mtk_ensure_kl_tab(mtk_ctx* ctx);
 // mtk_q_sample with the timesteps drawn in the kernel when t_out is given (written there for the kernels that follow; t is not read)
+// and a bf16 copy of x_in (same strides) when x16 is given
 int mtk_q_sample_t(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u, float* x_in,
-                   int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed, uint64_t row0, int64_t* t_out, hipStream_t stream);
+                   int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed, uint64_t row0, int64_t* t_out, uint16_t* x16, hipStream_t stream);
 int mtk_poison_bad_t(const int64_t* t, int64_t B, int T, float* p0, int64_t rs0, int64_t cs0, int n0, float* p1, int64_t rs1,
                      int64_t cs1, int n1, double* p2, hipStream_t s);
 

@@ -133,7 +133,15 @@ struct QSampleArgs {
     int32_t* xt_idx;
     uint64_t seed, row0;
     int64_t* t_out;  // non-null: the timestep is drawn here (mtk_draw_t) and written for the kernels that follow; t is not read
+    uint16_t* x16;   // non-null: a bf16 copy of x_in, same strides (the bf16 training iteration's weight-gradient operand)
 };
+// the bf16 copy's element, rounded as the GEMMs round an fp32 operand
+__device__ __forceinline__ void put16(uint16_t* p, int64_t i, float v) {
+    if (p) {
+        const __bf16 e = (__bf16)v;
+        p[i] = *reinterpret_cast<const uint16_t*>(&e);
+    }
+}
 
 template <bool LDS_ROWS>
 __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
@@ -146,11 +154,16 @@ __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
         const SchedRow sr = s.rows[t];
         const float* xr = a.x0 + row * a.x0_ld;
         float* xo = a.x_in + row * a.xi_rs;
+        uint16_t* xh = a.x16 ? a.x16 + row * a.xi_rs : nullptr;
+        const bool bad16 = tv < 0 || tv >= a.d.T;  // the fp32 rows are poisoned by the entry point, the bf16 copy here
+        const float qn16 = __builtin_nanf("");
         PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
         PhiloxU pu(a.seed, a.row0 + row, MTK_STREAM_U);
         for (int j = 0; j < Nn; ++j) {
             const float e = a.eps ? a.eps[row * Nn + j] : pn.normal(j);
-            xo[j * a.xi_cs] = sr.sqrt_acp * xr[j] + sr.sqrt_1m_acp * e;
+            const float xt = sr.sqrt_acp * xr[j] + sr.sqrt_1m_acp * e;
+            xo[j * a.xi_cs] = xt;
+            put16(xh, j * a.xi_cs, bad16 ? qn16 : xt);
         }
         for (int k = 0; k < C; ++k) {
             const int o = s.off[k], Kk = s.off[k + 1] - o;
@@ -166,7 +179,11 @@ __global__ __launch_bounds__(kBlock) void k_q_sample(QSampleArgs a) {
                 if (v > best || i == 0) { best = v; arg = i; }
             }
             a.xt_idx[(int64_t)k * a.B + row] = arg;
-            for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
+            for (int i = 0; i < Kk; ++i) {
+                const float v = (i == arg) ? 0.0f : MTK_LOG_TINY;
+                xo[(int64_t)(Nn + o + i) * a.xi_cs] = v;
+                put16(xh, (int64_t)(Nn + o + i) * a.xi_cs, bad16 ? qn16 : v);
+            }
         }
     }
 }
@@ -728,6 +745,7 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
         const bool bad_t = tv < 0 || tv >= a.d.T;
         const float qnan = __builtin_nanf("");
         float* xo = a.x_in + row * a.xi_rs;
+        uint16_t* xh = a.x16 ? a.x16 + row * a.xi_rs : nullptr;
         // first group of inputs in flight before anything is consumed
         float xv[kGroup], ev[kGroup];
 #pragma unroll
@@ -753,6 +771,7 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
                     const float e = a.eps ? ev[i] : pn.normal(j);
                     const float xt = sr.sqrt_acp * xv[i] + sr.sqrt_1m_acp * e;
                     xo[j * a.xi_cs] = bad_t ? qnan : xt;
+                    put16(xh, j * a.xi_cs, bad_t ? qnan : xt);
                 }
             }
 #pragma unroll
@@ -772,7 +791,11 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
                     if (v > best || i == 0) { best = v; arg = i; }
                 }
                 a.xt_idx[(int64_t)k * a.B + row] = arg;
-                for (int i = 0; i < Kk; ++i) xo[(int64_t)(Nn + o + i) * a.xi_cs] = bad_t ? qnan : ((i == arg) ? 0.0f : MTK_LOG_TINY);
+                for (int i = 0; i < Kk; ++i) {
+                    const float v = bad_t ? qnan : ((i == arg) ? 0.0f : MTK_LOG_TINY);
+                    xo[(int64_t)(Nn + o + i) * a.xi_cs] = v;
+                    put16(xh, (int64_t)(Nn + o + i) * a.xi_cs, v);
+                }
             }
             continue;
         }
@@ -802,7 +825,10 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_fast(QSampleArgs a) {
                     a.xt_idx[(int64_t)k * a.B + row] = arg;
                     float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
                     const float hot_v = bad_t ? qnan : 0.0f, cold_v = bad_t ? qnan : MTK_LOG_TINY;
-                    for (int c = 0; c < Kk; ++c) xc[c * a.xi_cs] = (c == arg) ? hot_v : cold_v;
+                    for (int c = 0; c < Kk; ++c) {
+                        xc[c * a.xi_cs] = (c == arg) ? hot_v : cold_v;
+                        put16(xh, (int64_t)(Nn + o + c) * a.xi_cs, (c == arg) ? hot_v : cold_v);
+                    }
                 }
             }
         }
@@ -830,11 +856,13 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_items(QSampleArgs a) {
     const float qnan = __builtin_nanf("");
     const SchedRow sr = a.d.rows[t];
     float* xo = a.x_in + row * a.xi_rs;
+    uint16_t* xh = a.x16 ? a.x16 + row * a.xi_rs : nullptr;
     if (item < Nn) {
         PhiloxNF pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
         const float e = a.eps ? a.eps[row * Nn + item] : pn.normal(item);
         const float xt = sr.sqrt_acp * xv + sr.sqrt_1m_acp * e;
         xo[item * a.xi_cs] = bad_t ? qnan : xt;
+        put16(xh, item * a.xi_cs, bad_t ? qnan : xt);
         return;
     }
     const int k = item - Nn;
@@ -855,7 +883,10 @@ __global__ __launch_bounds__(kBlock) void k_q_sample_items(QSampleArgs a) {
     a.xt_idx[(int64_t)k * a.B + row] = arg;
     float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
     const float hot_v = bad_t ? qnan : 0.0f, cold_v = bad_t ? qnan : MTK_LOG_TINY;
-    for (int c = 0; c < Kk; ++c) xc[c * a.xi_cs] = (c == arg) ? hot_v : cold_v;
+    for (int c = 0; c < Kk; ++c) {
+        xc[c * a.xi_cs] = (c == arg) ? hot_v : cold_v;
+        put16(xh, (int64_t)(Nn + o + c) * a.xi_cs, (c == arg) ? hot_v : cold_v);
+    }
 }
 
 struct TruePost { float lt_c0, lt_ct, w_c0, w_ct, w_cc, w_sum, self; };
@@ -1203,6 +1234,7 @@ struct LossGradArgs {
     // kl_tab = the [T][4] coefficient table of k_gauss_kl_rows (null: MSE), kscale = w_gauss / (Nn ln 2)
     const double* kl_tab;
     float kscale;
+    uint16_t* dout16;  // optional bf16 copy of dout, same layout (the bf16 training iteration's head weight-gradient operand)
     // optional device pair {w_multi, w_gauss} that multiplies the two scales (mtk_train_backward_dev: the weights of the two loss
     // sums are an autograd engine's incoming gradients, device scalars the host never reads); null: the scales stand as they are
     const float* w_dev;
@@ -1256,6 +1288,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
             const int t = mtk_tclamp(a.t[row], a.d.T);
             const float* mo = a.out + row;
             float* go = a.dout + row;
+            uint16_t* gh = a.dout16 ? a.dout16 + row : nullptr;
             PhiloxN pn(a.seed, a.row0 + row, MTK_STREAM_EPS);
             PhiloxNF pf(a.seed, a.row0 + row, MTK_STREAM_EPS);
             const SchedRow st = s.rows[t];
@@ -1267,6 +1300,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                     const float df = mo[j * ld] - e;
                     accg += df * df;
                     go[j * ld] = gscale * df;
+                    put16(gh, j * ld, gscale * df);
                 }
             } else {
                 // _vb_terms_bpd (GMD:431-484) and its derivative with respect to the predicted noise: the model mean is
@@ -1300,6 +1334,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                     }
                     accg += (float)term;
                     go[j * ld] = kscale * (float)grad;
+                    put16(gh, j * ld, kscale * (float)grad);
                 }
             }
             for (int k = w; k < C; k += kLgWaves) {
@@ -1371,7 +1406,9 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 MTK_LG_COLS(i) {
                     const float sm = ex<FAST>((MTK_LG_COL(i) - mx) - lsum);
                     const float gi = KC > 0 ? gq[KC > 0 ? i : 0] : gc[i * ld];
-                    gc[i * ld] = mscale * (gi - sm * G);
+                    const float gv = mscale * (gi - sm * G);
+                    gc[i * ld] = gv;
+                    put16(gh, (int64_t)(Nn + o + i) * ld, gv);
                 }
             }
         }
@@ -1523,11 +1560,12 @@ int mtk_ensure_kl_tab(mtk_ctx* ctx) {
 // internal (mtk_train.hip): per-record losses and d(mean loss)/d(out); out / dout column-major [D][ld]
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
-                         float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream) {
+                         float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream,
+                         uint16_t* dout16) {
     // d(w_gauss * sum_rows loss_gauss + w_multi * sum_rows loss_multi) / d out  (w_dev: both weights times the device pair)
     LossGradArgs a{ctx->dev(), B, out, ld, x0, x0_ld, xt_idx, eps, t, loss_multi, loss_gauss, dout,
                    ctx->Nn > 0 ? (float)(2.0 * w_gauss / ctx->Nn) : 0.0f,
-                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0, nullptr, 0.0f, w_dev};
+                   ctx->C > 0 ? (float)((double)ctx->T * w_multi / ctx->C) : 0.0f, seed, row0, nullptr, 0.0f, dout16, w_dev};
     if (ctx->train_gauss_kl && ctx->Nn > 0) {
         const int rc = mtk_ensure_kl_tab(ctx);
         if (rc) return rc;
@@ -1557,11 +1595,11 @@ extern "C" int mtk_q_sample(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0
                             const float* u, float* x_in, int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed,
                             uint64_t row0, mtk_stream stream) {
     if (ctx && B > 0 && !t) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
-    return mtk_q_sample_t(ctx, B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0, nullptr, (hipStream_t)stream);
+    return mtk_q_sample_t(ctx, B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mtk_q_sample_t(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, const int64_t* t, const float* eps, const float* u, float* x_in,
-                   int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed, uint64_t row0, int64_t* t_out, hipStream_t stream) {
+                   int64_t xi_rs, int64_t xi_cs, int32_t* xt_idx, uint64_t seed, uint64_t row0, int64_t* t_out, uint16_t* x16, hipStream_t stream) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null context");
     if (B == 0) return MTK_OK;  // empty batch: nothing to read (a framework's empty tensor has a null data pointer)
     if (B < 0 || !x0 || (!t && !t_out) || !x_in) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: null pointer or negative B");
@@ -1569,7 +1607,7 @@ int mtk_q_sample_t(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, cons
     if (x0_ld < ctx->Nn + ctx->C) MTK_FAIL(MTK_ERR_ARG, "mtk_q_sample: x0_ld %lld < Nn + C = %d", (long long)x0_ld, ctx->Nn + ctx->C);
     if (B == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
-    QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0, t_out};
+    QSampleArgs a{ctx->dev(), B, x0, x0_ld, t, eps, u, x_in, xi_rs, xi_cs, xt_idx, seed, row0, t_out, x16};
     const bool lds = ctx->T <= MTK_LDS_T_MAX && !getenv("MTK_NO_LDS_ROWS");
     // fast math: stage the row-major records through LDS when they are narrow and 16-byte aligned (the slab
     // replaces the LDS copy of the schedule rows, which then come from L2: measured equal)

@@ -20,7 +20,8 @@
 
 int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, const float* x0, int64_t x0_ld,
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
-                         float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream);  // mtk_diffusion.hip
+                         float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream,
+                         uint16_t* dout16 = nullptr);  // mtk_diffusion.hip
 
 namespace {
 
@@ -1045,7 +1046,7 @@ std::vector<MlpLayer*> layer_list(mtk_ctx* c) {
 
 void free_acts(TrainState& tr) {
     auto fr = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
-    fr(tr.xin); fr(tr.xt_idx); fr(tr.tdraw); fr(tr.out); fr(tr.dout); fr(tr.slab); fr(tr.slab_rs);
+    fr(tr.xin); fr(tr.xt_idx); fr(tr.tdraw); fr(tr.out); fr(tr.dout); fr(tr.slab); fr(tr.slab_rs); fr(tr.xin16); fr(tr.dout16);
     tr.t_drawn = false;
     for (auto& p : tr.dact) fr(p);
     tr.dact.clear();
@@ -1086,6 +1087,10 @@ int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     MTK_HIP(hipMalloc(&tr.dout, sizeof(float) * (size_t)Dp * Mpad));
     MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * Mpad, s));
     MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * Mpad, s));
+    MTK_HIP(hipMalloc(&tr.xin16, sizeof(uint16_t) * (size_t)Dp * Mpad));
+    MTK_HIP(hipMalloc(&tr.dout16, sizeof(uint16_t) * (size_t)Dp * Mpad));
+    MTK_HIP(hipMemsetAsync(tr.xin16, 0, sizeof(uint16_t) * (size_t)Dp * Mpad, s));
+    MTK_HIP(hipMemsetAsync(tr.dout16, 0, sizeof(uint16_t) * (size_t)Dp * Mpad, s));
     tr.xin_rows = tr.dout_rows = 0;
     tr.act.assign(1 + c->blocks.size(), nullptr);
     tr.dact.assign(1 + c->blocks.size(), nullptr);
@@ -1370,12 +1375,15 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     };
     if (do_fwd) {
     tr.fwd_rows = B;
-    if (B < tr.xin_rows) MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * ld, s));
+    if (B < tr.xin_rows) {
+        MTK_HIP(hipMemsetAsync(tr.xin, 0, sizeof(float) * (size_t)Dp * ld, s));
+        MTK_HIP(hipMemsetAsync(tr.xin16, 0, sizeof(uint16_t) * (size_t)Dp * ld, s));
+    }
     tr.xin_rows = B;
 
     // ---- forward, activations kept
     // xt_idx is addressed [C][B] by the kernels (row stride B)
-    if ((rc = mtk_q_sample_t(c, B, x0, x0_ld, t, eps, u, tr.xin, 1, ld, tr.xt_idx, seed, row0, t ? nullptr : tr.tdraw, s))) return rc;
+    if ((rc = mtk_q_sample_t(c, B, x0, x0_ld, t, eps, u, tr.xin, 1, ld, tr.xt_idx, seed, row0, t ? nullptr : tr.tdraw, st16 ? tr.xin16 : nullptr, s))) return rc;
     tr.t_drawn = !t;
     if (!t) t = tr.tdraw;
     {
@@ -1436,11 +1444,14 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         MTK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * n, s));
         MTK_HIP(hipMemsetAsync(tr.demb, 0, sizeof(float) * (size_t)tr.Tpad * c->emb_ld, s));
     }
-    if (B < tr.dout_rows) MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
+    if (B < tr.dout_rows) {
+        MTK_HIP(hipMemsetAsync(tr.dout, 0, sizeof(float) * (size_t)Dp * ld, s));
+        MTK_HIP(hipMemsetAsync(tr.dout16, 0, sizeof(uint16_t) * (size_t)Dp * ld, s));
+    }
     tr.dout_rows = B;
     // ---- loss and d loss / d out (column-major, rows >= B and features >= D stay zero)
     if ((rc = mtk_launch_loss_grad(c, B, tr.out, ld, x0, x0_ld, tr.xt_idx, eps, t, loss_multi, loss_gauss, tr.dout,
-                                   w_multi, w_gauss, w_dev, seed, row0, s)))
+                                   w_multi, w_gauss, w_dev, seed, row0, s, st16 ? tr.dout16 : nullptr)))
         return rc;
 
     // ---- backward
@@ -1579,7 +1590,8 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.bf16 = tr.bf16;
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
         g.A = tr.dout; g.lda = ld; g.B = act_of(nb); g.b16 = st16; g.ldb = l.in_pad;
-        if (st16) { g.B = f16(tr.act16t[nb]); g.ldb = Mpad; }
+        // bf16 mode: both operands bf16 along the batch (the loss-gradient kernel's bf16 copy of dout): the LDS-DMA GEMM
+        if (st16) { g.A = f16(tr.dout16); g.a16 = 1; g.B = f16(tr.act16t[nb]); g.ldb = Mpad; g.dma = l.in_pad % 64 == 0; }
         g.c_rs = l.in_pad; g.c_cs = 1;
         // db = row sums of dout [out_pad][Mpad] ride along (rows >= out are zero: the padding of the bias gradient is written too)
         if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<false, true>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
@@ -1604,7 +1616,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         g.bf16 = tr.bf16;
         g.M = l.out_pad; g.N = l.in_pad; g.K = (int)Mpad; wgrad_chunk(g);
         g.A = dact_of(0); g.a16 = st16; g.lda = l.out_pad; g.B = tr.xin; g.ldb = ld;
-        if (st16) { g.A = f16(tr.dact16t[0]); g.lda = Mpad; }
+        if (st16) { g.A = f16(tr.dact16t[0]); g.lda = Mpad; g.B = f16(tr.xin16); g.b16 = 1; g.dma = 1; }  // xin16: round_up(D, 128) rows
         g.c_rs = l.in_pad; g.c_cs = 1;
         if ((rc = wgrad(g, [&](const G2& q) { return st16 ? launch<false, false>(q, s) : launch<true, false>(q, s); }, grads + r.w_off, grads + r.b_off))) return rc;
         if ((rc = bucket_done())) return rc;
