@@ -201,6 +201,40 @@ def bench_mixed_loss(mtk, dev, rows):
             "note": "each kernel's time includes the 8 B/row pass that turns rows with an out-of-range timestep into NaN"}
 
 
+def bench_training(mtk, dev, hidden=1024, batch=2048, steps=200):
+    """BASELINE configs[4]'s per-rank shape (global batch 16,384 over 8 ranks = 2,048 rows, 4 x 1024, shape M): one
+    ClavaDDPMTrainer iteration = noising + forward + losses + backward + AdamW + EMA, in-kernel Philox noise and timesteps."""
+    K, Nn, T = np.array([10] * 10), 20, 1000
+    D = Nn + int(K.sum())
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.cat([torch.randn((batch, Nn), generator=g)] + [torch.randint(0, int(k), (batch, 1), generator=g).float() for k in K], 1).to(dev)
+    fl_fwd = flops_per_eval(D, 128, [hidden] * 4)
+    fl_step = batch * (3 * fl_fwd - 2 * D * 128)  # forward + data gradients + weight gradients; the input has no gradient
+    out = {"rows": batch, "denoiser": f"4x{hidden}", "rng": "philox (in-kernel, timesteps included)", "reductions": "deterministic",
+           "includes": "q_sample, forward, losses, backward, AdamW, EMA; no host-framework kernel in the iteration"}
+    for prec in ("bf16", "fp32"):
+        net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([hidden] * 4, 0.0))
+        d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
+        d.rng = "philox"
+        tr = mtk.ClavaDDPMTrainer(d, iter(()), 2e-4, 1e-4, steps, device=dev)
+        tr.set_train_precision(prec)
+        for _ in range(6):
+            tr._train_step(x0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr._train_step(x0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        peak = PEAK_TFLOPS["bf16" if prec == "bf16" else "fp32"]
+        out[prec] = {"ms_per_step": dt * 1e3, "rows_per_s": batch / dt,
+                     "roofline": {"bound": "mfma", "achieved": fl_step / dt / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_step / dt / 1e12 / peak,
+                                  "note": "whole iteration (33 dependent launches at 2,048 rows), not one kernel"}}
+        tr.finish()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -405,6 +439,7 @@ def main():
         out["sampled_rows_per_s_4x512"] = extras["sampling_4x512"]["sampled_rows_per_s"]
     if not a.no_extras and world == 1 and not strong:
         extras["mixed_loss_shapeM"] = bench_mixed_loss(mtk, dev, 1 << 20)
+        extras["training_2048x4x1024"] = bench_training(mtk, dev)
         for prec, nt_p in (("fp32", 10), ("bf16x3", 20)):  # the modes that carry the <= 1e-4 parity bar, same records
             if prec == a.precision:
                 continue
