@@ -578,7 +578,11 @@ __device__ __forceinline__ float lae_f(float a, float b) {
 __device__ __forceinline__ void normal2_fast(uint32_t a, uint32_t b, float& n0, float& n1) {
     const float u1 = ((float)(a >> 8) + 1.0f) * 0x1p-24f;
     const float u2 = (float)(b >> 8) * 0x1p-24f;
-    const float r = __fsqrt_rn(-2.0f * flog(u1));
+    // the v_sqrt_f32 instruction itself (1 ulp; its argument is 0 or >= 1.2e-7, no denormals): the header's __fsqrt_rn is OCML's
+    // "native" square root, which the compiler lowered to the bare instruction in one kernel and to the correctly rounded
+    // expansion in another - kernels that must draw the same noise (the lane-per-record and lane-per-item forms) then differed
+    // by an ulp in one value out of seven
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * flog(u1));
     n0 = r * __cosf(6.283185307179586f * u2);
     n1 = r * __sinf(6.283185307179586f * u2);
 }
@@ -1064,6 +1068,50 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     loss_rows_fast_body<LDS_ROWS, STAGE, kKCacheSmall, false>(a);
 }
 
+// One categorical block of a reverse step with in-kernel noise: the new state column = inverse CDF of
+// P_i = (A e_i + Bc) Q_i at the uniform u1 (see the notes above k_p_sample_step_fast).  Shared by the lane-per-record and the
+// lane-per-(record, item) kernels, which therefore draw the same columns.
+template <int KC>
+__device__ __forceinline__ int step_draw_block(const BlockRaw<KC>& raw, const float* mc, int64_t cs, int Kk, int cz, float acp1, float al, float logK,
+                                               float log_1m_alpha, float log_1m_acp_prev, int t, float u1) {
+    const float qc = fexp(log_1m_alpha - logK);
+    const float Qh = al + qc, Qc = qc;
+    const float Bc = (t == 0) ? 0.0f : fexp(log_1m_acp_prev - logK);
+    int arg = Kk - 1;
+    auto draw = [&](auto tag) {
+        const BlockExp<decltype(tag)::value, KC> be(raw, mc, cs, Kk);
+        const float A = acp1 * __builtin_amdgcn_rcpf(be.sum);
+        // inverse CDF: the first column whose running sum exceeds u * total = the number of columns whose running sum
+        // does not (P >= 0, the running sum never falls), capped at the last column - an add, a compare and a counted
+        // carry per column instead of a guarded select
+        int below = 0;
+        if constexpr (decltype(tag)::value) {
+            float Pv[KC], total = 0.0f;  // every P_i once (registers), then the search
+            be.each([&](int i, float e) {
+                Pv[i] = (A * e + Bc) * ((i == cz) ? Qh : Qc);
+                total += Pv[i];
+            });
+            const float target = u1 * total;
+            float cum = 0.0f;
+            be.each([&](int i, float) {
+                cum += Pv[i];
+                below += (cum <= target) ? 1 : 0;
+            });
+        } else {  // streamed block: sum_i (A e_i + Bc) Q_i in closed form (Q_i = Qc except at the current state), no pass
+            const float total = A * (Qc * be.sum + (Qh - Qc) * be.at(cz)) + Bc * (Qc * (float)Kk + (Qh - Qc));
+            const float target = u1 * total;
+            float cum = 0.0f;
+            be.each([&](int i, float e) {
+                cum += (A * e + Bc) * ((i == cz) ? Qh : Qc);
+                below += (cum <= target) ? 1 : 0;
+            });
+        }
+        arg = below < Kk - 1 ? below : Kk - 1;
+    };
+    if (Kk <= KC) draw(CachedTag{}); else draw(StreamTag{});
+    return arg;
+}
+
 template <int KC>
 __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
     const Staged s = stage_tables<false>(a.d);
@@ -1159,43 +1207,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                 nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
                 czn = a.z_idx[(int64_t)(k + 1) * a.B + row];
             }
-            const float logK = s.logK[k];
-            const float qc = fexp(a.log_1m_alpha - logK);
-            const float Qh = al + qc, Qc = qc;
-            const float Bc = (t == 0) ? 0.0f : fexp(a.log_1m_acp_prev - logK);
-            const float u1 = pu.uniform(k);
-            int arg = Kk - 1;
-            auto draw = [&](auto tag) {
-                const BlockExp<decltype(tag)::value, KC> be(raw, mc, a.mo_cs, Kk);
-                const float A = acp1 * __builtin_amdgcn_rcpf(be.sum);
-                // inverse CDF: the first column whose running sum exceeds u * total = the number of columns whose running sum
-                // does not (P >= 0, the running sum never falls), capped at the last column - an add, a compare and a counted
-                // carry per column instead of a guarded select
-                int below = 0;
-                if constexpr (decltype(tag)::value) {
-                    float Pv[KC], total = 0.0f;  // every P_i once (registers), then the search
-                    be.each([&](int i, float e) {
-                        Pv[i] = (A * e + Bc) * ((i == cz) ? Qh : Qc);
-                        total += Pv[i];
-                    });
-                    const float target = u1 * total;
-                    float cum = 0.0f;
-                    be.each([&](int i, float) {
-                        cum += Pv[i];
-                        below += (cum <= target) ? 1 : 0;
-                    });
-                } else {  // streamed block: sum_i (A e_i + Bc) Q_i in closed form (Q_i = Qc except at the current state), no pass
-                    const float total = A * (Qc * be.sum + (Qh - Qc) * be.at(cz)) + Bc * (Qc * (float)Kk + (Qh - Qc));
-                    const float target = u1 * total;
-                    float cum = 0.0f;
-                    be.each([&](int i, float e) {
-                        cum += (A * e + Bc) * ((i == cz) ? Qh : Qc);
-                        below += (cum <= target) ? 1 : 0;
-                    });
-                }
-                arg = below < Kk - 1 ? below : Kk - 1;
-            };
-            if (Kk <= KC) draw(CachedTag{}); else draw(StreamTag{});
+            const int arg = step_draw_block<KC>(raw, mc, a.mo_cs, Kk, cz, acp1, al, s.logK[k], a.log_1m_alpha, a.log_1m_acp_prev, t, pu.uniform(k));
             a.z_idx[(int64_t)k * a.B + row] = arg;
             if (xo) {
                 float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
@@ -1204,6 +1216,64 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
             raw = nxt;
             cz = czn;
         }
+    }
+}
+
+// The same step with one lane per (record, item), item = a numeric column or a categorical block (blockIdx.y), for the batch
+// sizes the reference's callers sample (1 k - 20 k rows per call, SYNTH:79): a lane-per-record launch of 1,024 rows is four
+// workgroups whose lanes each walk 30 items in a chain (22 us); spread over the items the chain is one item (k_q_sample_items
+// is the same idea).  In-kernel noise or injected Gaussian noise; injected uniforms stay with the kernel above.  Same
+// expressions, same draws: the two kernels' outputs are the same bits (tests/test_gpu_parity.py, MTK_STEP_ROWS).
+template <int KC>
+__global__ __launch_bounds__(kBlock) void k_p_sample_step_items(StepArgs a) {
+    const uint64_t seed_ = a.seed_src ? a.seed_src[0] : a.seed, row0_ = a.seed_src ? a.seed_src[1] : a.row0;
+    const int Nn = a.d.Nn, t = a.t;
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= a.B) return;
+    const int item = blockIdx.y;
+    const uint32_t stream_n = MTK_STREAM_STEP + 2u * (uint32_t)t, stream_u = stream_n + 1u;
+    const float* mo = a.mo + row * a.mo_rs;
+    float* xo = a.x_in ? a.x_in + row * a.xi_rs : nullptr;
+    if (item < Nn) {
+        const int j = item;
+        const float eh = mo[j * a.mo_cs];
+        const double zj = a.z[(int64_t)j * a.B + row];
+        double nz;
+        if (a.noise) {
+            nz = a.noise_f64 ? reinterpret_cast<const double*>(a.noise)[row * Nn + j] : (double)reinterpret_cast<const float*>(a.noise)[row * Nn + j];
+        } else {
+            PhiloxNF pn(seed_, row0_ + row, stream_n);
+            nz = (double)pn.normal(j);
+        }
+        double mean;
+        if (a.first) {
+            const float zf = (float)zj;
+            const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
+            mean = (double)(a.coef1 * x0h + a.coef2 * zf);
+        } else {
+            const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
+            mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+        }
+        if (a.grad) mean = (double)(float)mean + a.variance * (double)a.grad[row * Nn + j];
+        const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
+        a.z[(int64_t)j * a.B + row] = zn;
+        if (xo) xo[j * a.xi_cs] = (float)zn;
+        return;
+    }
+    const int k = item - Nn;
+    const int o = a.d.off[k], Kk = a.d.off[k + 1] - o;
+    const float* mc = mo + (int64_t)(Nn + o) * a.mo_cs;
+    BlockRaw<KC> raw;
+    raw.load(mc, a.mo_cs, Kk);
+    const int cz = a.z_idx[(int64_t)k * a.B + row];
+    PhiloxW pu(seed_, row0_ + row, stream_u);
+    const float acp1 = (t == 0) ? 1.0f : fexp(a.log_acp_prev);
+    const float al = fexp(a.log_alpha);
+    const int arg = step_draw_block<KC>(raw, mc, a.mo_cs, Kk, cz, acp1, al, a.d.logK[k], a.log_1m_alpha, a.log_1m_acp_prev, t, pu.uniform(k));
+    a.z_idx[(int64_t)k * a.B + row] = arg;
+    if (xo) {
+        float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
+        for (int i = 0; i < Kk; ++i) xc[i * a.xi_cs] = (i == arg) ? 0.0f : MTK_LOG_TINY;
     }
 }
 
@@ -1691,6 +1761,13 @@ extern "C" int mtk_p_sample_step_guided(mtk_ctx* ctx, int64_t B, int t, int firs
     a.mo = model_out; a.mo_rs = mo_rs; a.mo_cs = mo_cs;
     a.z = z; a.z_idx = z_idx; a.noise = noise; a.noise_f64 = noise_is_f64; a.u = u;
     a.x_in = x_in_next; a.xi_rs = xi_rs; a.xi_cs = xi_cs; a.seed = seed; a.row0 = row0; a.seed_src = ctx->seed_src;
+    // caller-sized batches: one lane per (record, item); MTK_STEP_ROWS keeps the lane-per-record kernel (A/B switch of the tests)
+    if (ctx->fast_math && !u && B <= kItemsMaxRows && ctx->Nn + ctx->C > 0 && ctx->Nn + ctx->C <= 65535 && !getenv("MTK_STEP_ROWS")) {
+        auto kitems = max_levels(ctx) <= kKCacheSmall ? k_p_sample_step_items<kKCacheSmall> : k_p_sample_step_items<kKCache>;
+        hipLaunchKernelGGL(kitems, dim3((unsigned)((B + kBlock - 1) / kBlock), (unsigned)(ctx->Nn + ctx->C)), dim3(kBlock), 0, (hipStream_t)stream, a);
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
+    }
     auto kstep = !ctx->fast_math ? k_p_sample_step : (max_levels(ctx) <= kKCacheSmall ? k_p_sample_step_fast<kKCacheSmall> : k_p_sample_step_fast<kKCache>);
     hipLaunchKernelGGL(kstep, dim3(grid_for(B)), dim3(kBlock), lds_bytes(ctx, false),
                        (hipStream_t)stream, a);

@@ -750,6 +750,147 @@ __global__ __launch_bounds__(256) void k_x_to_bf16(uint16_t* dst, int ld, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (round 3).  A reverse step for 1 k - 8 k rows — what the reference's callers sample per call (SYNTH:79) —
+// gives k_gemm_bf16 4 ... 32 row tiles: 16 ... 128 of 256 CUs each walk a whole K = 1024 k-loop (24 us) per layer, 139 us a
+// step.  k_gemm_bf16_s is the same product on 64 x 64 tiles: (rows / 64) x (N / 64) workgroups of 4 waves (a wave = 32
+// records x 32 features), both operands L2 -> LDS by LDS-DMA into a four-stage ring (three k-blocks requested ahead, one
+// barrier per k-block; the ring of k_gemm2c in mtk_train.hip), two workgroups per CU.  Same arithmetic as the big tile, bit
+// for bit: weights are the A operand and records the B operand of the same MFMA over the same 16-wide k-steps in the same
+// order, accumulators start from the bias, the epilogue is k_gemm_bf16's (time embedding, ReLU, bf16 rounding,
+// v_permlane32_swap pairing, 16-byte stores) — tests/test_gpu_parity.py holds the two against each other with torch.equal.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRingS = 4;
+constexpr int64_t kSmallRowsMax = 4096;  // passes of at most this many (padded) rows (measured, 4 x 1024: 1.7 x at 1 k - 2 k rows, 1.2 x at 4 k,
+                                         // 0.8 x at 8 k: from there the 256 x 256 tiles fill enough of the chip and pull a quarter of the bytes)
+constexpr int kStageS = 2 * 64 * 128;  // bytes: record tile (64 rows x 128 B) | weight tile
+extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
+
+template <bool OF32, bool EMB>
+__global__ __launch_bounds__(256) void k_gemm_bf16_s(GemmB g) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int nk = g.Kpad / BK;
+
+    // accumulators start from the bias: the lane's features are 8 q + 4 hh + [0, 4) of the wave's 32
+    f32x16 acc;
+    {
+        const float* bp = g.bias + n0 + wc * 32 + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+        }
+    }
+    int tr = 0;
+    float4 eq[4];  // first layer with per-record timesteps: the record's embedding row, requested before the k-loop
+    const int64_t row = m0 + wr * 32 + li;
+    if (EMB) {
+        tr = (g.tvec && row < g.M) ? mtk_tclamp(g.tvec[row], g.T) : (g.tvec ? 0 : g.t_scalar);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wc * 32 + 8 * q + 4 * hh;
+            eq[q] = n < g.emb_ld ? *reinterpret_cast<const float4*>(g.emb + (int64_t)tr * g.emb_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // the values above are in registers before the first DMA request: the vmcnt arithmetic below counts DMA pieces only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // wave wv moves rows [16 wv, 16 wv + 16) of both tiles: two 8-row pieces per operand and k-block
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    const int lr = lane >> 3;
+    unsigned voff_x[2], voff_w[2];  // [piece]: row in tile = 16 wv + 8 j + lr, its swizzle key (row >> 1) & 7 = (4 j + (lr >> 1)) & 7
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lc = (lane & 7) ^ ((4 * j + (lr >> 1)) & 7);
+        voff_x[j] = (unsigned)(lr * g.x_ld * 2 + lc * 16);
+        voff_w[j] = (unsigned)(lr * g.w_ld * 2 + lc * 16);
+    }
+    const unsigned char* x_base = reinterpret_cast<const unsigned char*>(g.X) + (m0 + 16 * wv) * g.x_ld * 2;
+    const unsigned char* w_base = reinterpret_cast<const unsigned char*>(g.W) + ((int64_t)n0 + 16 * wv) * g.w_ld * 2;
+    auto issue = [&](int i) {  // k-block i into stage i % kRingS
+        const unsigned dst = (unsigned)((i % kRingS) * kStageS + wv * 2048);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned char* gx = x_base + (int64_t)j * 8 * g.x_ld * 2 + (int64_t)i * 128;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_x[j]), "s"(gx), "s"(dst + j * 1024u) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned char* gw = w_base + (int64_t)j * 8 * g.w_ld * 2 + (int64_t)i * 128;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_w[j]), "s"(gw), "s"(dst + 8192u + j * 1024u) : "memory");
+        }
+    };
+    for (int i = 0; i < kRingS - 1 && i < nk; ++i) issue(i);
+    for (int i = 0; i < nk; ++i) {
+        // k-block i has landed when at most the requests made after it are outstanding: min(kRingS - 2, nk - 1 - i) blocks of 4 pieces
+        const int after = nk - 1 - i;
+        if (after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's pieces of block i are in LDS, and every wave is done reading block i - 1's stage
+        if (i + kRingS - 1 < nk) issue(i + kRingS - 1);
+        const unsigned char* st = gs_smem + (i % kRingS) * kStageS;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kp = 2 * ks + hh;
+            const int rx = wr * 32 + li, rw = wc * 32 + li;
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + rx * 128 + ((kp ^ ((rx >> 1) & 7)) * 16));
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(st + 8192 + rw * 128 + ((kp ^ ((rw >> 1) & 7)) * 16));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+        }
+    }
+    // epilogue of k_gemm_bf16 for one 32 x 32 sub-tile: record = lane & 31, features 8 q + 4 (lane >> 5) + [0, 4)
+    unsigned pk[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wc * 32 + 8 * q + 4 * hh;
+        float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        if (EMB) { v[0] += eq[q].x; v[1] += eq[q].y; v[2] += eq[q].z; v[3] += eq[q].w; }
+        if (g.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+        }
+        if (OF32) {
+            float* yf = reinterpret_cast<float*>(g.Y);
+            if (row < g.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < g.N) yf[row * g.y_rs + (int64_t)(n + j) * g.y_cs] = v[j];
+            }
+        } else {
+            const __bf16 e[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            pk[q][0] = reinterpret_cast<const unsigned*>(e)[0];
+            pk[q][1] = reinterpret_cast<const unsigned*>(e)[1];
+        }
+    }
+    if (!OF32) {
+        uint16_t* yb = reinterpret_cast<uint16_t*>(g.Y) + row * g.y_rs + n0 + wc * 32;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][0], pk[2 * p2][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][1], pk[2 * p2][1], false, false);
+            *reinterpret_cast<uint4*>(yb + 8 * (2 * p2 + (hh ? 0 : 1))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+    }
+}
+
+template <bool OF32, bool EMB>
+int launch_small(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
+    constexpr int kBytes = kRingS * kStageS;  // 64 KiB: two workgroups per CU
+    static bool attr[64] = {};
+    if (device < 0 || device >= 64 || !attr[device]) {
+        MTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_bf16_s<OF32, EMB>), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+        if (device >= 0 && device < 64) attr[device] = true;
+    }
+    if (Mpad % 64 || Npad % 64 || g.Kpad % BK || Mpad / 64 > 65535 * 32) MTK_FAIL(MTK_ERR_STATE, "layered bf16 GEMM (small tiles): %lld x %d x %d", (long long)Mpad, Npad, g.Kpad);
+    hipLaunchKernelGGL((k_gemm_bf16_s<OF32, EMB>), dim3((unsigned)(Mpad / 64), (unsigned)(Npad / 64)), dim3(256), kBytes, s, g);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
+}
+
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 int n_cus_layered(int device) {
@@ -959,6 +1100,8 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
             MTK_HIP(hipGetLastError());
         }
         int cur = 0;
+        // small passes take the 64 x 64-tile kernel (k_gemm_bf16_s: same bits, all CUs busy from 1 k rows on); MTK_LAYERED_BIG: A/B switch
+        const bool small = !SPLIT && Mpad <= kSmallRowsMax && !getenv("MTK_LAYERED_BIG");
         // one timestep for the whole launch (plain bf16): proj is folded into the first block, whose bias is row t of embf_l
         const bool fold = !SPLIT && !t && c->wb16_fold && c->embf_l && t_scalar >= 0 && t_scalar < c->T;
         int ld = kp0;
@@ -970,7 +1113,7 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
             g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar; g.T = c->T;
             ld = round_up(c->proj.out_pad, BT);
             g.Y = ws[cur ^ 1]; g.y_rs = (int64_t)F * ld; g.y_lo = ld;
-            if ((rc = launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s))) return rc;
+            if ((rc = small ? launch_small<false, true>(g, c->device, Mpad, ld, s) : launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s))) return rc;
             cur ^= 1;
         }
         for (size_t i = 0; i < c->blocks.size(); ++i) {
@@ -998,7 +1141,7 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
             h.bias = folded ? c->embf_l + (size_t)t_scalar * c->embf_ld : c->bb16[1 + i]; h.relu = 1;
             ld = round_up(l.out_pad, BT);
             h.Y = ws[cur ^ 1]; h.y_rs = (int64_t)F * ld; h.y_lo = ld;
-            if ((rc = launch<false, 2, 4, false, SPLIT>(h, c->device, Mpad, ld, s))) return rc;
+            if ((rc = small ? launch_small<false, false>(h, c->device, Mpad, ld, s) : launch<false, 2, 4, false, SPLIT>(h, c->device, Mpad, ld, s))) return rc;
             cur ^= 1;
         }
         GemmB h{};
@@ -1006,7 +1149,8 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         h.X = ws[cur]; h.x_ld = (int64_t)F * ld; h.x_lo = ld;
         h.W = reinterpret_cast<const uint16_t*>(wimg.back()); h.w_ld = (int64_t)F * h.Kpad; h.bias = c->bb16.back();
         h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
-        if (c->head.out <= 128) rc = launch<true, 4, 2, false, SPLIT>(h, c->device, Mpad, 128, s);
+        if (small) rc = launch_small<true, false>(h, c->device, Mpad, c->head.out <= 128 ? 128 : round_up(c->head.out_pad, BT), s);
+        else if (c->head.out <= 128) rc = launch<true, 4, 2, false, SPLIT>(h, c->device, Mpad, 128, s);
         else rc = launch<true, 2, 4, false, SPLIT>(h, c->device, Mpad, round_up(c->head.out_pad, BT), s);
         if (rc) return rc;
     }

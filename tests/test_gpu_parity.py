@@ -936,6 +936,75 @@ def test_mlp_forward_bf16_layered(shape):
     assert torch.equal(o2.t().contiguous(), out)
 
 
+@pytest.mark.parametrize("K,Nn", [([10] * 10, 20), ([3, 12, 16, 2], 5), ([4, 30, 7], 3), ([0], 24), ([4, 9, 16], 0)])
+def test_caller_sized_reverse_step_equals_the_general_kernel(monkeypatch, K, Nn):
+    """Round 3: for at most 16,384 rows a reverse step with in-kernel noise runs one lane per (record, item)
+    (k_p_sample_step_items) instead of one lane per record.  Same expressions and draws (the block draw is one shared function):
+    under the A/B switch MTK_STEP_ROWS the new state - fp64 numeric columns, category codes, the next input matrix - is the same
+    bit for bit, at the first step (fp32 mean, GMD first-step semantics), in the middle, at t = 0, with classifier guidance and
+    with injected Gaussian noise.  Blocks of 12 / 16 levels sit on the register variants' edges, 30 is streamed."""
+    import midst_toolkit_amd as mtk
+
+    K = np.asarray(K)
+    C = 0 if int(K[0]) == 0 else len(K)
+    D, T, B = Nn + int(K.sum()), 50, 1337
+    torch.manual_seed(5)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([128, 128], 0.0))
+    d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev()).to(dev())
+    eng = d.engine()
+    eng.set_math("fast")
+    g = torch.Generator().manual_seed(9)
+    out = (torch.randn((D, B), generator=g) * 2.0).to(dev())
+    z0 = torch.randn((max(Nn, 1), B), generator=g, dtype=torch.float64).to(dev())
+    zi0 = torch.stack([torch.randint(0, int(k), (B,), generator=g) for k in (K if C else [1])]).to(torch.int32).to(dev())
+    grad = torch.randn((B, Nn), generator=g).to(dev()) if Nn else None
+    noise = torch.randn((B, Nn), generator=g, dtype=torch.float64).to(dev()) if Nn else None
+
+    def run():
+        res = []
+        for t, first, gr, nz in ((T - 1, 1, None, None), (17, 0, None, None), (0, 0, None, None), (23, 0, grad, None), (31, 0, None, noise)):
+            z, zi, x = z0.clone(), zi0.clone(), torch.zeros((D, B), device=dev())
+            eng.p_sample_step(B, t, first, out, (1, B), z, zi, nz, None, x, (1, B), seed=77, row0=4096, grad=gr)
+            res.append((z, zi, x))
+        return res
+
+    new = run()
+    monkeypatch.setenv("MTK_STEP_ROWS", "1")
+    old = run()
+    for a, b in zip(new, old):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if C:
+        assert not torch.equal(new[1][1], zi0)  # the step did draw
+
+
+@pytest.mark.parametrize("shape,B", [((120, [1024] * 4), 1000), ((120, [1024] * 4), 4096), ((142, [512, 1024, 1024, 1024, 1024, 512]), 3900),
+                                     ((40, [128, 256]), 77)])
+def test_small_pass_layered_kernel_equals_the_big_tile(monkeypatch, shape, B):
+    """Round 3: passes of at most 4,096 rows run the layered denoiser on 64 x 64 tiles (k_gemm_bf16_s: every CU busy from 1 k rows
+    on - the batch sizes the reference's callers sample, SYNTH:79) instead of 256 x 256.  A re-tiling, not other arithmetic: same
+    MFMA, same k order, accumulators started from the bias, the same epilogue - under the A/B switch MTK_LAYERED_BIG the outputs
+    are the same bits, with per-record timesteps (time embedding gathered in the first block's epilogue) and with one timestep
+    per launch (proj folded into the first block)."""
+    import midst_toolkit_amd as mtk
+
+    D, layers = shape
+    params = orc.init_mlp_params(D, layers, seed=3)
+    net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(layers), 0.0)).to(dev())
+    net.load_state_dict(params, strict=True)
+    net.precision = "bf16"
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((B, D), generator=g).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev())
+    eng = net.engine(dev())
+    small = [eng.mlp_forward(x, t, precision="bf16"), eng.mlp_forward(x, 417, precision="bf16")]
+    monkeypatch.setenv("MTK_LAYERED_BIG", "1")
+    big = [eng.mlp_forward(x, t, precision="bf16"), eng.mlp_forward(x, 417, precision="bf16")]
+    for a, b in zip(small, big):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    want = orc.mlp_forward(params, x.cpu()[:300], t.cpu()[:300])
+    assert float((small[0].cpu()[:300] - want).abs().max()) <= BF16_TOL * float(want.abs().max())
+
+
 @pytest.mark.parametrize("shape", [(20, [512] * 4), (120, [512] * 4), (120, [1024] * 4), (142, [512, 1024, 1024, 1024, 1024, 512]), (40, [128, 256])])
 def test_mlp_forward_bf16_one_timestep_launches(shape):
     """Launches that carry ONE timestep (every step of the reverse chain passes an integer, not a vector) run proj folded
