@@ -1,12 +1,13 @@
 #!/bin/bash
 # tools/profile_round.sh <tag>: on the GPU box (through gpurun), the rocprofv3 evidence of a round:
-#   1. --kernel-trace --stats of the default `python3 bench.py` command            -> gpurun_out/<tag>/bench_*_kernel_stats.csv + bench.json
+#   1. the default `python3 bench.py` command, plain (-> bench.json) and under --kernel-trace --stats (-> bench_*_kernel_stats.csv)
 #   2. separate --pmc passes (FETCH_SIZE; WRITE_SIZE) of the same command, short    -> gpurun_out/<tag>/pmc_bench_{fetch,write}/
 #   3. --kernel-trace --stats of benchmarks/bench_train_sample.py --train-only      -> gpurun_out/<tag>/train_*_kernel_stats.csv
 #   4. --pmc passes of benchmarks/bench_kernels.py (the three HBM kernels)          -> gpurun_out/<tag>/pmc_kernels_{fetch,write}/
 #   5. the training iteration at config 5's per-rank shape (2,048 x 4x1024, bf16), kernel stats and plain timings
 #   6. the layered 4x1024 denoiser in chain mode (one timestep per launch): kernel stats and --pmc FETCH_SIZE / WRITE_SIZE passes
-#   7. small-batch reverse chains (1,024 / 8,192 rows, eager vs graph) and the state-input vs matrix-input chain
+#   7. small-batch reverse chains (1,024 ... 16,384 rows, eager vs graph; caller-sized vs general kernels; kernel stats at 1,024 rows)
+#      and the state-input vs matrix-input chain
 # Each step runs under its own time limit; a step that times out or aborts ends the script.
 set -uo pipefail
 tag=${1:-prof}
@@ -23,8 +24,11 @@ step() {  # name seconds command...
   echo "   rc=$rc $(tail -n 1 "$out/$name.log" | cut -c1-200)"
   case $rc in 124|137|134|139) echo "!! $name ended with $rc: stopping"; exit $rc;; esac
 }
+# the line itself without the profiler (kernel tracing costs the launch-bound extras up to 50 %), then the same command traced
+step bench_plain 400 python3 "$root/bench.py"
+grep '^{' "$out/bench_plain.log" | tail -n 1 > "$out/bench.json"
 step bench_stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench_stats" -o bench -- python3 "$root/bench.py"
-grep '^{' "$out/bench_stats.log" | tail -n 1 > "$out/bench.json"
+grep '^{' "$out/bench_stats.log" | tail -n 1 > "$out/bench_traced.json"
 step pmc_bench_fetch 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_bench_fetch" -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras
 step pmc_bench_write 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_bench_write" -o pmc -- python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras
 step train_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/train_stats" -o train -- python3 "$root/benchmarks/bench_train_sample.py" --train-only
@@ -34,8 +38,12 @@ step train1024_fp32 200 python3 "$root/benchmarks/bench_train_sample.py" --train
 step layered_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/layered_stats" -o layered -- python3 "$root/benchmarks/bench_layered.py" --rows 262144 --one-t
 step pmc_layered_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_layered_fetch" -o pmc -- python3 "$root/benchmarks/bench_layered.py" --rows 262144 --one-t
 step pmc_layered_write 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_layered_write" -o pmc -- python3 "$root/benchmarks/bench_layered.py" --rows 262144 --one-t
-step graph_chain_512 300 python3 "$root/benchmarks/bench_graph.py" --hidden 512 --rows 1024,8192
-step graph_chain_1024 300 python3 "$root/benchmarks/bench_graph.py" --hidden 1024 --rows 1024,8192
+step graph_chain_512 300 python3 "$root/benchmarks/bench_graph.py" --hidden 512 --rows 1024,2048,4096,8192,16384
+step graph_chain_1024 300 python3 "$root/benchmarks/bench_graph.py" --hidden 1024 --rows 1024,2048,4096,8192,16384
+# the same chains with the general kernels at every batch size (A/B switches): the "before" of the caller-sized kernels, same box
+step graph_chain_512_general 300 env MTK_LAYERED_BIG=1 MTK_STEP_ROWS=1 python3 "$root/benchmarks/bench_graph.py" --hidden 512 --rows 1024,8192
+step graph_chain_1024_general 300 env MTK_LAYERED_BIG=1 MTK_STEP_ROWS=1 python3 "$root/benchmarks/bench_graph.py" --hidden 1024 --rows 1024,8192
+step small_chain_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/small_chain_stats" -o small_chain -- python3 "$root/benchmarks/bench_graph.py" --hidden 1024 --rows 1024
 step chain_state 300 python3 "$root/benchmarks/bench_chain.py"
 step kernels_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kernels_stats" -o kernels -- python3 "$root/benchmarks/bench_kernels.py"
 step pmc_kernels_fetch 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_kernels_fetch" -o pmc -- python3 "$root/benchmarks/bench_kernels.py" --hbm-only
