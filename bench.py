@@ -18,6 +18,8 @@ other modes, each with its own roofline fraction, measured after the timed regio
   sampling_4x512 / sampling_4x1024  sampled rows/s at T = 1000, shape M (20 numeric + 10 x 10 categorical), every rank
   mixed_loss_shapeM                 evals/s of q_sample -> denoiser -> loss_rows at shape M with the three kernels' rates
   parity_fp32 / parity_bf16x3       the headline workload in the two modes that carry the 1e-4 parity bar
+  training_2048x4x1024              one ClavaDDPMTrainer iteration at BASELINE configs[4]'s per-rank shape, bf16 and fp32 GEMMs
+  sampling_caller_sized             microseconds per reverse step at 1,024 / 8,192 rows (what the reference's callers sample per call)
 """
 import argparse
 import json
@@ -164,6 +166,30 @@ def bench_sampling(mtk, dev, hidden, rows, dist, world, comm=False, warm_rows=No
             "roofline_step": {"bound": "hbm", "achieved": rows * b_step / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": rows * b_step / t_step / 1e9 / HBM_PEAK_GBS, "kernel_ms": t_step * 1e3, "bytes_per_row_step": b_step},
             "whole_loop_mfma_frac": rows * T * fl / dt / 1e12 / PEAK_TFLOPS["bf16"]}
+
+
+def bench_sampling_small(mtk, dev):
+    """Reverse chains at the batch sizes the reference's callers sample per call (SYNTH:79: 1 k - 20 k rows): microseconds per
+    reverse step (denoiser + posterior step) at T = 1000, shape M, in-kernel Philox noise, bf16 denoiser."""
+    K, Nn, T = np.array([10] * 10), 20, 1000
+    D = Nn + int(K.sum())
+    out = {"T": T, "rng": "philox (in-kernel)", "math": "fast", "unit": "us per reverse step"}
+    for hidden in (512, 1024):
+        torch.manual_seed(0)
+        net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([hidden] * 4, 0.0))
+        net.precision = "bf16"
+        d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
+        d.precision, d.rng, d.results_on_device = "bf16", "philox", True
+        for rows in (1024, 8192):
+            d.sample(rows, torch.ones(1), seed=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x, _ = d.sample(rows, torch.ones(1), seed=2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert bool(torch.isfinite(x).all())
+            out[f"4x{hidden}_{rows}_rows"] = {"us_per_step": dt / T * 1e6, "sampled_rows_per_s": rows / dt}
+    return out
 
 
 def bench_mixed_loss(mtk, dev, rows):
@@ -440,6 +466,7 @@ def main():
     if not a.no_extras and world == 1 and not strong:
         extras["mixed_loss_shapeM"] = bench_mixed_loss(mtk, dev, 1 << 20)
         extras["training_2048x4x1024"] = bench_training(mtk, dev)
+        extras["sampling_caller_sized"] = bench_sampling_small(mtk, dev)
         for prec, nt_p in (("fp32", 10), ("bf16x3", 20)):  # the modes that carry the <= 1e-4 parity bar, same records
             if prec == a.precision:
                 continue
