@@ -313,6 +313,13 @@ int mtk_train_step(mtk_ctx* ctx, int64_t B, const float* x0, int64_t x0_ld, cons
  *    one workgroup on the iteration's side stream).  NULL (default) switches it off. */
 int mtk_train_set_loss_means(mtk_ctx* ctx, float* means_dev);
 int mtk_train_timesteps(mtk_ctx* ctx, int64_t B, int64_t* t_dev, mtk_stream stream);
+/* No reference counterpart (an execution detail of TRAINER:88-94 on one device): with deferred reduction on, mtk_train_step
+ * (deterministic mode, no bucket events) leaves the split-batch partial sums of the weight / bias gradients in its slabs and
+ * mtk_train_apply's optimizer pass adds them - in the same order, so the same bits - as it reads the gradient, writing the sums
+ * to image 1 on the way: one launch and one pass over the gradient image fewer per iteration.  Between the two calls image 1
+ * is incomplete; mtk_train_export(image 1) and switching the mode off complete it first.  Not for multi-GPU runs, whose
+ * all-reduce reads image 1 between the two calls.  Off by default. */
+int mtk_train_set_deferred_reduce(mtk_ctx* ctx, int on, mtk_stream stream);
 /* No reference counterpart beyond the reference pipeline's torch.use_deterministic_algorithms (common/random.py:11-55): on
  * (default) = the split-batch reductions of the weight gradients are added in a fixed order (partial tiles in slabs) and the
  * time-embedding scatter accumulates in 64-bit fixed point, so gradients are bit-identical run to run; off = fp32 hardware

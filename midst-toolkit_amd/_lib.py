@@ -69,6 +69,7 @@ _SIGS = {
     "mtk_train_set_label_classes": (C.c_int, [_p, _i32]),
     "mtk_train_set_labels": (C.c_int, [_p, _p]),
     "mtk_train_set_loss_means": (C.c_int, [_p, _p]),
+    "mtk_train_set_deferred_reduce": (C.c_int, [_p, C.c_int, _p]),
     "mtk_train_timesteps": (C.c_int, [_p, C.c_int64, _p, _p]),
     "mtk_train_dropout_mask": (C.c_int, [_p, _i32, _i64, _u64, _p, _p]),
     "mtk_train_forward": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _u64, _u64, _p]),

@@ -49,6 +49,17 @@ struct MlpLayer {
     bool owned = true;            // false while the layer reads from an attached training image
 };
 
+// Split-batch partials of an iteration's weight / bias gradients: segment i of the gradient image (dst, 4 n4 floats) is the sum,
+// in slice order, of `splits` slices of a slab (slice stride 4 n4 floats).  splits = 0: nothing to add, dst already holds the gradient.
+constexpr int MTK_MAX_SEGS = 48;
+struct MtkSegs {
+    int n;
+    float* dst[MTK_MAX_SEGS];
+    const float* slab[MTK_MAX_SEGS];
+    int splits[MTK_MAX_SEGS];
+    int64_t n4[MTK_MAX_SEGS];
+};
+
 // Training state (mtk_train.hip, a19).  The five parameter images (weights, gradients, Adam m, Adam v, EMA) live in
 // ONE caller-owned buffer so the host can all-reduce the gradient image; activations are context-owned.
 struct TrainLayerRef {
@@ -120,6 +131,11 @@ struct TrainState {
     float* slab_rs = nullptr;   // [splits][out_pad]
     size_t slab_rs_elems = 0;
     long long* demb_fix = nullptr;  // [Tpad][emb_ld] fixed-point accumulator of the time-embedding gradient
+    // mtk_train_set_deferred_reduce: mtk_train_step leaves the split-batch partials in the slabs (`pending`) and mtk_train_apply's
+    // optimizer pass adds them as it reads the gradient (and writes the sums to the gradient image): one launch and one pass over
+    // the gradient image fewer per iteration.  Anything else that reads the image first (mtk_train_export) adds them itself.
+    bool defer_reduce = false, segs_pending = false;
+    MtkSegs pending;
 };
 
 struct mtk_ctx {

@@ -22,6 +22,7 @@ int mtk_launch_loss_grad(mtk_ctx* ctx, int64_t B, const float* out, int64_t ld, 
                          const int32_t* xt_idx, const float* eps, const int64_t* t, float* loss_multi, float* loss_gauss,
                          float* dout, double w_multi, double w_gauss, const float* w_dev, uint64_t seed, uint64_t row0, hipStream_t stream,
                          uint16_t* dout16 = nullptr);  // mtk_diffusion.hip
+static int materialize_grads(mtk_ctx* c, hipStream_t s);
 
 namespace {
 
@@ -843,14 +844,8 @@ __global__ __launch_bounds__(256) void k_scatter_emb(const void* dact, int64_t l
 }
 // dst[i] = sum over the `splits` slices of a slab region, slices added in index order (run-to-run identical), 4 floats per
 // thread; one launch serves every weight / bias gradient of the iteration (blockIdx.y = segment).
-constexpr int kMaxSegs = 48;
-struct ReduceSegs {
-    int n;
-    float* dst[kMaxSegs];
-    const float* slab[kMaxSegs];
-    int splits[kMaxSegs];
-    int64_t n4[kMaxSegs];  // floats / 4 per slice (= slice stride / 4)
-};
+constexpr int kMaxSegs = MTK_MAX_SEGS;
+typedef MtkSegs ReduceSegs;  // mtk_common.h: n4 = floats / 4 per slice (= slice stride / 4)
 __global__ __launch_bounds__(256) void k_reduce_splits(ReduceSegs r) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int sg = blockIdx.y;
@@ -985,6 +980,58 @@ __global__ __launch_bounds__(256) void k_adamw_ema(AdamArgs a) {
     }
 }
 
+// The same update per segment of the image (blockIdx.y), four elements per thread, with the split-batch partials of the segment's
+// gradient added on the way in (slice order, as k_reduce_splits adds them: the same sums) and the sum written to the gradient image.
+// splits = 0: the gradient is read from the image.  Same arithmetic per element as k_adamw_ema.
+__global__ __launch_bounds__(256) void k_adamw_ema_segs(AdamArgs a, float* gw, MtkSegs r) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int sg = blockIdx.y;
+    const int64_t n4 = r.n4[sg];
+    const float* slab = r.slab[sg];
+    const int splits = r.splits[sg];
+    const int64_t base = r.dst[sg] - gw;  // element offset of the segment in an image
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = base + 4 * i;
+        v4f g;
+        if (splits > 0) {
+            g = *reinterpret_cast<const v4f*>(slab + 4 * i);
+            int z = 1;
+            for (; z + 8 <= splits; z += 8) {
+                v4f q[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const v4f*>(slab + ((int64_t)(z + j) * n4 + i) * 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g += q[j];
+            }
+            for (; z < splits; ++z) g += *reinterpret_cast<const v4f*>(slab + ((int64_t)z * n4 + i) * 4);
+            *reinterpret_cast<v4f*>(gw + e) = g;
+        } else {
+            g = *reinterpret_cast<const v4f*>(gw + e);
+        }
+        v4f p = *reinterpret_cast<const v4f*>(a.p + e), m = *reinterpret_cast<const v4f*>(a.m + e), v = *reinterpret_cast<const v4f*>(a.v + e);
+        v4f em = *reinterpret_cast<const v4f*>(a.ema + e);
+        unsigned short h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float pc = p[c] * a.decay;
+            float mc = m[c];
+            mc = mc + a.beta1_c * (g[c] - mc);
+            const float vc = v[c] * a.beta2 + a.beta2_c * g[c] * g[c];
+            const float denom = sqrtf(vc) / a.bc2_sqrt + a.eps;
+            pc = pc - a.step_size * (mc / denom);
+            p[c] = pc; m[c] = mc; v[c] = vc;
+            em[c] = em[c] * a.ema_rate + a.ema_c * pc;
+            const __bf16 b = (__bf16)pc;
+            h[c] = *reinterpret_cast<const unsigned short*>(&b);
+        }
+        *reinterpret_cast<v4f*>(a.p + e) = p;
+        *reinterpret_cast<v4f*>(a.m + e) = m;
+        *reinterpret_cast<v4f*>(a.v + e) = v;
+        *reinterpret_cast<v4f*>(a.ema + e) = em;
+        if (a.p16) *reinterpret_cast<uint2*>(a.p16 + e) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    }
+}
+
 // image <-> caller tensors (unpadded [out][in] / [out])
 __global__ void k_unpad(const float* src, int ld, float* dst, int rows, int cols) {
     const int64_t n = (int64_t)rows * cols;
@@ -1074,6 +1121,10 @@ int splits_for(int64_t K, int tiles) {
 int ensure_acts(mtk_ctx* c, int64_t Mpad, hipStream_t s) {
     TrainState& tr = c->train;
     if (Mpad <= tr.cap) return MTK_OK;
+    {   // partials left for the optimizer pass live in the slabs that are about to be freed
+        const int rc = materialize_grads(c, s);
+        if (rc) return rc;
+    }
     MTK_HIP(hipStreamSynchronize(s));
     free_acts(tr);
     ++c->ws_gen;
@@ -1222,6 +1273,8 @@ void mtk_free_train(mtk_ctx* c) {
     tr.dlab_fix = nullptr;
     tr.yvec = nullptr;
     tr.loss_means = nullptr;
+    tr.segs_pending = false;
+    tr.defer_reduce = false;
     tr.n_label = 0;
     tr.label_l = MlpLayer();
     free_acts(tr);
@@ -1462,6 +1515,7 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
     // weight-gradient GEMM, split-K over the batch: deterministic (partial tiles to slabs, added in order) or fp32 atomics
     ReduceSegs segs;
     segs.n = 0;
+    tr.segs_pending = false;  // partials of an iteration that was never applied: this backward overwrites the slabs
     size_t slab_used = 0, slab_rs_used = 0;
     auto wgrad = [&](G2& g, auto launcher, float* dw, float* db) -> int {
         const int splits = (g.K + g.kchunk - 1) / g.kchunk;
@@ -1626,8 +1680,13 @@ static int train_phases(mtk_ctx* c, int64_t B, const float* x0, int64_t x0_ld, c
         seg_mark = 0;
         segs.n = temb_segs;
         if ((rc = bucket_done())) return rc;
-    } else if (segs.n > 0) {  // every split-batch partial of the iteration, added in slice order by one launch
-        hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)segs.n), dim3(256), 0, s, segs);
+    } else if (segs.n > 0) {  // every split-batch partial of the iteration, added in slice order by one launch ...
+        if (tr.defer_reduce) {  // ... or by the optimizer pass that follows (mtk_train_set_deferred_reduce)
+            tr.pending = segs;
+            tr.segs_pending = true;
+        } else {
+            hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)segs.n), dim3(256), 0, s, segs);
+        }
     }
     MTK_HIP(hipGetLastError());
     return MTK_OK;
@@ -1672,6 +1731,27 @@ extern "C" int mtk_train_set_bucket_events(mtk_ctx* c, int n, void* const* event
         }
         tr.bucket_events[i] = (hipEvent_t)events[i];
     }
+    return MTK_OK;
+}
+
+// adds partials that mtk_train_step left for the optimizer pass (deferred reduction) when something else needs the gradient image first
+static int materialize_grads(mtk_ctx* c, hipStream_t s) {
+    TrainState& tr = c->train;
+    if (!tr.segs_pending) return MTK_OK;
+    hipLaunchKernelGGL(k_reduce_splits, dim3(256, (unsigned)tr.pending.n), dim3(256), 0, s, tr.pending);
+    MTK_HIP(hipGetLastError());
+    tr.segs_pending = false;
+    return MTK_OK;
+}
+
+extern "C" int mtk_train_set_deferred_reduce(mtk_ctx* c, int on, mtk_stream stream) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_train_set_deferred_reduce: null context");
+    MTK_HIP(hipSetDevice(c->device));
+    if (!on) {
+        const int rc = materialize_grads(c, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    c->train.defer_reduce = on != 0;
     return MTK_OK;
 }
 
@@ -1805,13 +1885,44 @@ extern "C" int mtk_train_apply(mtk_ctx* c, double lr, double weight_decay, doubl
         MTK_HIP(hipEventRecord(tr.ev_fork, s));
         MTK_HIP(hipStreamWaitEvent(ss, tr.ev_fork, 0));
     }
-    a.beg0 = t_beg; a.len0 = t_end - t_beg; a.beg1 = 0; a.n = a.len0;
-    hipLaunchKernelGGL(k_adamw_ema, dim3(64), dim3(256), 0, ss, a);
-    int rc = refresh_emb(c, ss);
-    if (rc) return rc;
-    if (ss != s) MTK_HIP(hipEventRecord(tr.ev_join, ss));
-    a.beg0 = 0; a.len0 = t_beg; a.beg1 = t_end; a.n = (int64_t)n - (t_end - t_beg);
-    hipLaunchKernelGGL(k_adamw_ema, dim3(1024), dim3(256), 0, s, a);
+    int rc;
+    if (tr.segs_pending) {
+        // deferred reduction: the optimizer pass runs segment by segment and adds each segment's split-batch partials as it reads the
+        // gradient.  Layers without partials (the label embedding: its gradient is written directly) enter with splits = 0.
+        float* gw = tr.state + n;
+        MtkSegs side{}, mainl{};
+        auto add = [&](float* dst, const float* slab, int splits, int64_t n4) -> int {
+            const int64_t off = dst - gw;
+            MtkSegs& q = (off >= t_beg && off < t_end) ? side : mainl;
+            if (q.n >= MTK_MAX_SEGS) MTK_FAIL(MTK_ERR_STATE, "mtk_train_apply: more than %d gradient segments", MTK_MAX_SEGS);
+            q.dst[q.n] = dst; q.slab[q.n] = slab; q.splits[q.n] = splits; q.n4[q.n] = n4;
+            ++q.n;
+            return MTK_OK;
+        };
+        for (int i = 0; i < tr.pending.n; ++i)
+            if ((rc = add(tr.pending.dst[i], tr.pending.slab[i], tr.pending.splits[i], tr.pending.n4[i]))) return rc;
+        for (auto& lr : tr.layers) {
+            bool have_w = false, have_b = false;
+            for (int i = 0; i < tr.pending.n; ++i) {
+                have_w = have_w || tr.pending.dst[i] == gw + lr.w_off;
+                have_b = have_b || tr.pending.dst[i] == gw + lr.b_off;
+            }
+            if (!have_w && (rc = add(gw + lr.w_off, nullptr, 0, (int64_t)lr.l->out_pad * lr.l->in_pad / 4))) return rc;
+            if (!have_b && (rc = add(gw + lr.b_off, nullptr, 0, (int64_t)lr.l->out_pad / 4))) return rc;
+        }
+        tr.segs_pending = false;
+        if (side.n > 0) hipLaunchKernelGGL(k_adamw_ema_segs, dim3(16, (unsigned)side.n), dim3(256), 0, ss, a, gw, side);
+        if ((rc = refresh_emb(c, ss))) return rc;
+        if (ss != s) MTK_HIP(hipEventRecord(tr.ev_join, ss));
+        if (mainl.n > 0) hipLaunchKernelGGL(k_adamw_ema_segs, dim3(128, (unsigned)mainl.n), dim3(256), 0, s, a, gw, mainl);
+    } else {
+        a.beg0 = t_beg; a.len0 = t_end - t_beg; a.beg1 = 0; a.n = a.len0;
+        hipLaunchKernelGGL(k_adamw_ema, dim3(64), dim3(256), 0, ss, a);
+        if ((rc = refresh_emb(c, ss))) return rc;
+        if (ss != s) MTK_HIP(hipEventRecord(tr.ev_join, ss));
+        a.beg0 = 0; a.len0 = t_beg; a.beg1 = t_end; a.n = (int64_t)n - (t_end - t_beg);
+        hipLaunchKernelGGL(k_adamw_ema, dim3(1024), dim3(256), 0, s, a);
+    }
     MTK_HIP(hipGetLastError());
     if ((rc = refresh_w16t(c, s))) return rc;
     if (ss != s) MTK_HIP(hipStreamWaitEvent(s, tr.ev_join, 0));
@@ -1825,6 +1936,10 @@ extern "C" int mtk_train_export(mtk_ctx* c, int image, float* const* W, float* c
     hipStream_t s = (hipStream_t)stream;
     MTK_HIP(hipSetDevice(c->device));
     TrainState& tr = c->train;
+    if (image == 1) {
+        const int rc = materialize_grads(c, s);
+        if (rc) return rc;
+    }
     const float* img = tr.state + (size_t)image * tr.n_img;
     for (size_t i = 0; i < tr.layers.size(); ++i) {
         const MlpLayer& l = *tr.layers[i].l;

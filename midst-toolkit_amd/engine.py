@@ -332,6 +332,12 @@ class Engine:
         self._loss_means = means
         check(_lib.lib().mtk_train_set_loss_means(self._h, ptr(means)))
 
+    def train_set_deferred_reduce(self, on: bool) -> None:
+        """Single-device training: train_step leaves the split-batch partials of the gradients to train_apply's optimizer pass
+        (mtk_train_set_deferred_reduce); the gradient image is complete after train_apply or train_export("grads")."""
+        with torch.cuda.device(self.device):
+            check(_lib.lib().mtk_train_set_deferred_reduce(self._h, int(bool(on)), self._stream()))
+
     def train_timesteps(self, B: int) -> torch.Tensor:
         """The timesteps the last iteration drew itself (train_step with ``t=None``; mtk_train_timesteps)."""
         t = torch.empty((B,), dtype=torch.int64, device=self.device)

@@ -133,6 +133,11 @@ class ClavaDDPMTrainer:
         lg = rows[1] if rows is not None else (torch.empty((B,), dtype=torch.float32, device=x0.device) if eng.Nn > 0 else None)
         means = torch.empty((2,), dtype=torch.float32, device=x0.device)  # a fresh pair per iteration: the caller may keep what is returned
         eng.train_set_loss_means(means)
+        # one device: nothing reads the gradient image between the backward and the optimizer pass, which then adds the split-batch
+        # partials itself (same order, same bits; one launch fewer).  Switched per iteration: direct engine calls keep the default.
+        defer = self._exchange is None
+        if defer:
+            eng.train_set_deferred_reduce(True)
         eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
         eng.train_set_loss_means(None)
         if self._exchange is not None:  # the one exchange of an iteration, bucket by bucket under the backward
@@ -141,6 +146,8 @@ class ClavaDDPMTrainer:
         g = self.optimizer.param_groups[0]
         self.optimizer.steps_done += 1
         eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
+        if defer:
+            eng.train_set_deferred_reduce(False)
         return means[0], means[1]
 
     # ------------------------------------------------------------------ TRAINER:96

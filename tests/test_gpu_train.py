@@ -510,6 +510,40 @@ def test_library_draws_the_timesteps_and_takes_the_batch_means():
     assert (float(lm), float(lg)) == keep  # a fresh pair per iteration: what was returned earlier is not overwritten
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deferred_reduction_gives_the_same_training_run(precision):
+    """Round 3: on one device ClavaDDPMTrainer lets the optimizer pass add the split-batch partials of the gradients
+    (mtk_train_set_deferred_reduce: k_adamw_ema_segs instead of k_reduce_splits + k_adamw_ema).  Same sums in the same order, same
+    per-element update: after several iterations all five images (weights, gradients, both Adam moments, EMA) are the same bits
+    as with the separate reduction; an export of the gradients between the two calls completes the image itself; a larger batch
+    arriving while partials are pending (the slabs are reallocated) does not lose them."""
+    c = dict(K=[10] * 10, Nn=20, T=1000, D=120, d_layers=[256, 512, 256])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    B = 1500
+    x0, t, eps, u = [v.to(dev()) for v in big_batch(c, B)]
+    x1 = big_batch(c, 4000, seed=6)[0].to(dev())
+    states = []
+    for defer in (False, True):
+        tr, d = build_trainer(c, p0)
+        eng = tr._engine
+        eng.train_set_precision(precision)
+        eng.set_math("fast")
+        for step in range(1, 5):
+            eng.train_set_deferred_reduce(defer)
+            eng.train_step(x0, t, None, None, 1.0 / B, None, None, seed=100 + step)
+            if step == 2:  # something else reads the gradient image first
+                g_mid = export(tr, "grads")
+            if step == 3:  # the slabs move while partials are pending
+                eng.train_forward(x1, torch.zeros(4000, dtype=torch.int64, device=dev()), None, None, seed=1)
+            eng.train_apply(2e-3, 1e-4, step, (0.9, 0.999), 1e-8, 0.999)
+            eng.train_set_deferred_reduce(False)
+        states.append((tr.state.clone(), g_mid))
+    assert torch.equal(states[0][0], states[1][0])
+    for k in states[0][1]:
+        assert torch.equal(states[0][1][k], states[1][1][k]), k
+    assert float(states[0][0][1].abs().sum()) > 0
+
+
 def test_adamw_ema_kernel():
     c = load_train("B_ragged")
     p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
