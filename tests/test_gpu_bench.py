@@ -39,6 +39,10 @@ def test_bench_line_single_gpu():
     ml = ex["mixed_loss_shapeM"]
     assert ml["evals_per_s"] > 0 and all(0 < ml[k]["frac"] < 1 for k in ("roofline_q_sample", "roofline_loss_rows", "roofline_denoiser"))
     assert ex["parity_fp32"]["evals_per_s"] > 0 and ex["parity_bf16x3"]["evals_per_s"] > ex["parity_fp32"]["evals_per_s"]
+    trn = ex["training_2048x4x1024"]  # one trainer iteration at configs[4]'s per-rank shape, both GEMM precisions
+    assert 0 < trn["bf16"]["ms_per_step"] < trn["fp32"]["ms_per_step"] and trn["rows"] == 2048
+    small = ex["sampling_caller_sized"]  # microseconds per reverse step at the batch sizes the reference's callers sample
+    assert all(small[k]["us_per_step"] > 0 for k in ("4x512_1024_rows", "4x512_8192_rows", "4x1024_1024_rows", "4x1024_8192_rows"))
 
 
 def test_bench_two_rank_rehearsal():
