@@ -97,6 +97,13 @@ int mtk_ctx_create(int device, int T, int Nn, int C, const int32_t* K_host, cons
 void mtk_ctx_destroy(mtk_ctx* ctx);
 /* No reference counterpart: selects enum mtk_math for this context's diffusion kernels. */
 int mtk_ctx_set_math(mtk_ctx* ctx, int mode);
+/* The constructor arguments gaussian_parametrization / parametrization of GaussianMultinomialDiffusion (GMD:164-165, 199-201).
+ * gaussian_x0 != 0 = GaussianParametrization.X0: the denoiser's numeric output is the predicted x_0 itself (GMD:404-405) - read
+ * by the reverse steps (ancestral, DDIM, reverse DDIM), the KL Gaussian loss and its gradient; the MSE loss compares the output
+ * with the noise either way (GMD:531-532).  multinomial_direct != 0 = Parametrization.DIRECT: the per-block log-softmax of the
+ * categorical output is log p(x_{t-1} | x_t) itself, no posterior (GMD:828-829) - read by the reverse step, the multinomial
+ * loss and its gradient.  Defaults 0 / 0 = EPS / X0, the reference's. */
+int mtk_ctx_set_parametrization(mtk_ctx* ctx, int gaussian_x0, int multinomial_direct);
 
 /* No reference counterpart (capture-ready contract): sizes every workspace of the context for calls of up to
  * max_rows rows through the denoiser (B for mtk_mlp_forward and the training entry points, B * P for mtk_tf_score).  Afterwards

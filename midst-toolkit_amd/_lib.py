@@ -34,6 +34,7 @@ _SIGS = {
     "mtk_ctx_create": (C.c_int, [_i32, _i32, _i32, _i32, _p, _p, _p, C.POINTER(_p)]),
     "mtk_ctx_destroy": (None, [_p]),
     "mtk_ctx_set_math": (C.c_int, [_p, _i32]),
+    "mtk_ctx_set_parametrization": (C.c_int, [_p, _i32, _i32]),
     "mtk_ctx_reserve": (C.c_int, [_p, _i64, _p]),
     "mtk_ctx_set_seed_source": (C.c_int, [_p, _p]),
     "mtk_ctx_workspace_generation": (_i64, [_p]),

@@ -35,6 +35,8 @@ struct DevTables {
     const int32_t* off;    // [C+1] one-hot column offsets
     const float* logK;     // [C]
     int T, Nn, C, S;
+    int gx0, direct;  // GaussianParametrization.X0 (the denoiser's numeric output is x_0, GMD:404) / Parametrization.DIRECT (its
+                      // per-block log-softmax is the reverse distribution itself, GMD:828): mtk_ctx_set_parametrization
 };
 
 constexpr int MTK_LDS_T_MAX = 2048;  // schedule rows are staged in LDS up to this T (64 KB)
@@ -167,6 +169,7 @@ struct mtk_ctx {
     uint64_t n_malloc = 0;  // hipMalloc calls made by mtk_alloc (mtk_ctx_alloc_count)
     bool pooling = false;  // mtk_release keeps blocks (inside mtk_mlp_set_weights) or frees them (everywhere else)
     bool fast_math = false;  // MTK_MATH_FAST: diffusion kernels on hardware transcendentals, exact block LSE
+    int gauss_x0 = 0, direct = 0;  // mtk_ctx_set_parametrization
     // denoiser
     bool have_weights = false;
     int dim_t = 0, n_hidden = 0;
@@ -211,7 +214,7 @@ struct mtk_ctx {
     size_t tf_pack_elems = 0;
     TrainState train;
 
-    DevTables dev() const { return DevTables{d_rows, d_off, d_logK, T, Nn, C, S}; }
+    DevTables dev() const { return DevTables{d_rows, d_off, d_logK, T, Nn, C, S, gauss_x0, direct}; }
     double tab(int which, int t) const { return tables[(size_t)which * T + t]; }
 };
 

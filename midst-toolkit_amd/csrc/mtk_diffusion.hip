@@ -254,8 +254,12 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
             const float lsum = logf(sum);
             // block maxima of the two unnormalised posteriors (the shift of the fp64 sums): the model term is
             // increasing in the logit, so its maximum sits at the arg-max logit or at the sampled x_t
+            // Parametrization.DIRECT (GMD:828-829): the block's log-softmax IS log p(x_{t-1} | x_t) - no posterior, no whole-row
+            // log-sum-exp on the model side
+            const bool direct = a.d.direct != 0;
             auto un_model = [&](int i) {
                 const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                if (direct) return lsm;
                 const float ev = (t == 0) ? lsm : lae(lsm + s1.log_acp, ce);
                 return ev + ((i == ct) ? q_hot : q_cold);
             };
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_rows(LossArgs a) {
                 b_t += exp((double)un_t - (double)m_t);
                 b_m += exp((double)un_model(i) - (double)m_m);
             }
-            const float lse_t = scan_t.close_block(b_t, m_t), lse_m = scan_m.close_block(b_m, m_m);
+            const float lse_t = scan_t.close_block(b_t, m_t), lse_m = direct ? 0.0f : scan_m.close_block(b_m, m_m);
             // prior term q(x_T | x_0) vs uniform (GMD:887)
             const float cT = srT.log_1m_acp - logK;
             const float p_hot = lae(0.0f + srT.log_acp, cT), p_cold = lae(MTK_LOG_TINY + srT.log_acp, cT);
@@ -333,13 +337,15 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
                 nz = (double)pn.normal(j);
             }
             double mean;
+            // GaussianParametrization.X0 (GMD:404-405): the output is the predicted x_0 itself
             if (a.first) {  // z is still fp32: torch forms the mean in fp32 (SURVEY finding 0.4)
                 const float zf = (float)zj;
-                const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
+                const float x0h = a.d.gx0 ? eh : a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
                 mean = (double)(a.coef1 * x0h + a.coef2 * zf);
             } else {  // fp32 coefficient x fp64 state promotes; the eps term is an fp32 product
+                // (X0: coefficient and output are both fp32, their product is formed in fp32 before the fp64 state promotes the sum)
                 const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
-                mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+                mean = (a.d.gx0 ? (double)(a.coef1 * eh) : (double)a.coef1 * x0h) + (double)a.coef2 * zj;
             }
             if (a.grad) mean = (double)(float)mean + a.variance * (double)a.grad[row * Nn + j];
             const double mask = (t != 0) ? 1.0 : 0.0;
@@ -365,15 +371,17 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step(StepArgs a) {
             float sum = 0.0f;
             for (int i = 0; i < Kk; ++i) sum += expf(mc[i * a.mo_cs] - mx);
             const float lsum = logf(sum);
+            const bool direct = a.d.direct != 0;  // GMD:828-829: the log-softmax is the reverse distribution, no posterior
             auto un = [&](int i) {
                 const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
+                if (direct) return lsm;
                 const float ev = (t == 0) ? lsm : lae(lsm + a.log_acp_prev, ce);
                 return ev + ((i == cz) ? q_hot : q_cold);
             };
             const float m = fmaxf(un(amax), un(cz));
             double b = 0.0;
             for (int i = 0; i < Kk; ++i) b += exp((double)un(i) - (double)m);
-            const float lse = scan.close_block(b, m);
+            const float lse = direct ? 0.0f : scan.close_block(b, m);
             float best = -INFINITY;
             int arg = 0;
             for (int i = 0; i < Kk; ++i) {
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
         for (int j = 0; j < Nn; ++j) {
             double* zp = a.z + (int64_t)j * a.B + row;
             const float zf = (float)*zp, eh = mo[j * a.mo_cs];
-            float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;             // GMD:545 _predict_features_start_from_eps
+            float x0h = a.d.gx0 ? eh : a.sqrt_recip * zf - a.sqrt_recipm1 * eh;  // GMD:399-405: from eps (GMD:545), or the output itself
             if (a.grad) {                                                    // condition_score, GMD:649-655
                 float e = (a.sqrt_recip * zf - x0h) / a.sqrt_recipm1;
                 e = e - a.sqrt_1m_ab * a.grad[row * Nn + j];
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_ddim_step(DdimArgs a) {
 // gaussian_ddim_reverse_step (GMD:1160-1186): the deterministic DDIM map run towards noise, numeric features only, fp32.
 struct DdimRevArgs {
     int64_t B;
-    int Nn;
+    int Nn, gx0;
     float sqrt_recip, sqrt_recipm1, c_x0, c_eps;  // sqrt(alpha_bar_next), sqrt(1 - alpha_bar_next)
     const float* mo; int64_t mo_rs, mo_cs;
     double* z;
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_ddim_reverse_step(DdimRevArgs a) {
         for (int j = 0; j < a.Nn; ++j) {
             double* zp = a.z + (int64_t)j * a.B + row;
             const float zf = (float)*zp, eh = a.mo[row * a.mo_rs + j * a.mo_cs];
-            const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;     // GMD:1177 -> 545
+            const float x0h = a.gx0 ? eh : a.sqrt_recip * zf - a.sqrt_recipm1 * eh;  // GMD:1177 -> 399-405
             const float eps = (a.sqrt_recip * zf - x0h) / a.sqrt_recipm1;  // GMD:1179-1182
             const float zn = x0h * a.c_x0 + a.c_eps * eps;                 // GMD:1186
             *zp = (double)zn;
@@ -957,7 +965,10 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
         if (!multi) continue;
         const SchedRow st = s.rows[t];
         const SchedRow s1 = s.rows[t > 0 ? t - 1 : 0];
-        const float acp1 = (t == 0) ? 1.0f : fexp(s1.log_acp);
+        // Parametrization.DIRECT (GMD:828-829): the model side is the block's softmax itself - P_i = e_i / sum e, i.e. A = 1 / sum,
+        // Bc = 0, Q = 1 in the probability-space form below; the true posterior is unchanged
+        const bool direct = a.d.direct != 0;
+        const float acp1 = (t == 0 || direct) ? 1.0f : fexp(s1.log_acp);
         float kl = 0.0f, nll = 0.0f, prior = 0.0f;
         int Kc = -1;
         TruePost tpE{}, tpN{};
@@ -975,9 +986,9 @@ __device__ __forceinline__ void loss_rows_fast_body(const LossArgs& a) {
                 const float ce = s1.log_1m_acp - logK;
                 e_hot = (t == 0) ? 0.0f : lae_f(0.0f + s1.log_acp, ce);
                 e_cold = (t == 0) ? MTK_LOG_TINY : lae_f(MTK_LOG_TINY + s1.log_acp, ce);
-                Bc = (t == 0) ? 0.0f : fexp(ce);
-                Qh = fexp(q_hot);
-                Qc = fexp(q_cold);
+                Bc = (t == 0 || direct) ? 0.0f : fexp(ce);
+                Qh = direct ? 1.0f : fexp(q_hot);
+                Qc = direct ? 1.0f : fexp(q_cold);
                 const float cT = srT.log_1m_acp - logK;
                 const float p_hot = lae_f(0.0f + srT.log_acp, cT), p_cold = lae_f(MTK_LOG_TINY + srT.log_acp, cT);
                 prior_k = fexp(p_hot) * (p_hot + logK) + (float)(Kk - 1) * (fexp(p_cold) * (p_cold + logK));
@@ -1073,10 +1084,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 // lane-per-(record, item) kernels, which therefore draw the same columns.
 template <int KC>
 __device__ __forceinline__ int step_draw_block(const BlockRaw<KC>& raw, const float* mc, int64_t cs, int Kk, int cz, float acp1, float al, float logK,
-                                               float log_1m_alpha, float log_1m_acp_prev, int t, float u1) {
+                                               float log_1m_alpha, float log_1m_acp_prev, int t, float u1, bool direct) {
+    // Parametrization.DIRECT (GMD:828-829): the softmax itself is the reverse distribution - P_i = e_i, i.e. Q = 1 and Bc = 0
     const float qc = fexp(log_1m_alpha - logK);
-    const float Qh = al + qc, Qc = qc;
-    const float Bc = (t == 0) ? 0.0f : fexp(log_1m_acp_prev - logK);
+    const float Qh = direct ? 1.0f : al + qc, Qc = direct ? 1.0f : qc;
+    const float Bc = (t == 0 || direct) ? 0.0f : fexp(log_1m_acp_prev - logK);
     int arg = Kk - 1;
     auto draw = [&](auto tag) {
         const BlockExp<decltype(tag)::value, KC> be(raw, mc, cs, Kk);
@@ -1154,11 +1166,11 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                     double mean;
                     if (a.first) {
                         const float zf = (float)zj;
-                        const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh[i];
+                        const float x0h = a.d.gx0 ? eh[i] : a.sqrt_recip * zf - a.sqrt_recipm1 * eh[i];
                         mean = (double)(a.coef1 * x0h + a.coef2 * zf);
                     } else {
                         const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh[i]);
-                        mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+                        mean = (a.d.gx0 ? (double)(a.coef1 * eh[i]) : (double)a.coef1 * x0h) + (double)a.coef2 * zj;
                     }
                     if (a.grad) mean = (double)(float)mean + a.variance * (double)a.grad[row * Nn + j];
                     const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
@@ -1186,7 +1198,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                 for (int i = 0; i < Kk; ++i) {
                     const float lsm = (mc[i * a.mo_cs] - mx) - lsum;
                     const float ev = (t == 0) ? lsm : lae_f(lsm + a.log_acp_prev, ce);
-                    const float v = gumbel_fast(a.u[row * S + o + i]) + (ev + ((i == czk) ? q_hot : q_cold));
+                    const float v = gumbel_fast(a.u[row * S + o + i]) + (a.d.direct ? lsm : ev + ((i == czk) ? q_hot : q_cold));
                     if (v > best || i == 0) { best = v; arg = i; }
                 }
                 a.z_idx[(int64_t)k * a.B + row] = arg;
@@ -1207,7 +1219,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_fast(StepArgs a) {
                 nxt.load(mo + (int64_t)(Nn + o + Kk) * a.mo_cs, a.mo_cs, s.off[k + 2] - (o + Kk));
                 czn = a.z_idx[(int64_t)(k + 1) * a.B + row];
             }
-            const int arg = step_draw_block<KC>(raw, mc, a.mo_cs, Kk, cz, acp1, al, s.logK[k], a.log_1m_alpha, a.log_1m_acp_prev, t, pu.uniform(k));
+            const int arg = step_draw_block<KC>(raw, mc, a.mo_cs, Kk, cz, acp1, al, s.logK[k], a.log_1m_alpha, a.log_1m_acp_prev, t, pu.uniform(k), a.d.direct != 0);
             a.z_idx[(int64_t)k * a.B + row] = arg;
             if (xo) {
                 float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
@@ -1248,11 +1260,11 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_items(StepArgs a) {
         double mean;
         if (a.first) {
             const float zf = (float)zj;
-            const float x0h = a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
+            const float x0h = a.d.gx0 ? eh : a.sqrt_recip * zf - a.sqrt_recipm1 * eh;
             mean = (double)(a.coef1 * x0h + a.coef2 * zf);
         } else {
             const double x0h = (double)a.sqrt_recip * zj - (double)(a.sqrt_recipm1 * eh);
-            mean = (double)a.coef1 * x0h + (double)a.coef2 * zj;
+            mean = (a.d.gx0 ? (double)(a.coef1 * eh) : (double)a.coef1 * x0h) + (double)a.coef2 * zj;
         }
         if (a.grad) mean = (double)(float)mean + a.variance * (double)a.grad[row * Nn + j];
         const double zn = mean + ((t != 0) ? a.sigma : 0.0) * nz;
@@ -1269,7 +1281,7 @@ __global__ __launch_bounds__(kBlock) void k_p_sample_step_items(StepArgs a) {
     PhiloxW pu(seed_, row0_ + row, stream_u);
     const float acp1 = (t == 0) ? 1.0f : fexp(a.log_acp_prev);
     const float al = fexp(a.log_alpha);
-    const int arg = step_draw_block<KC>(raw, mc, a.mo_cs, Kk, cz, acp1, al, a.d.logK[k], a.log_1m_alpha, a.log_1m_acp_prev, t, pu.uniform(k));
+    const int arg = step_draw_block<KC>(raw, mc, a.mo_cs, Kk, cz, acp1, al, a.d.logK[k], a.log_1m_alpha, a.log_1m_acp_prev, t, pu.uniform(k), a.d.direct != 0);
     a.z_idx[(int64_t)k * a.B + row] = arg;
     if (xo) {
         float* xc = xo + (int64_t)(Nn + o) * a.xi_cs;
@@ -1379,12 +1391,13 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 const float c1 = (float)tb[0], c2 = (float)tb[1];
                 const double lv1 = (double)(float)tb[2], lv2 = tb[3];
                 const double e2 = exp(-lv2), half_head = 0.5 * (((-1.0 + lv2) - lv1) + exp(lv1 - lv2)), inv_stdv = exp(-(0.5 * lv2));
-                const float slope = c1 * st.sqrt_recipm1_acp;  // = -d mean / d eps_hat
+                // GaussianParametrization.X0 (GMD:404-405): the output is x_0_hat itself, d mean / d out = c1
+                const float slope = a.d.gx0 ? -c1 : c1 * st.sqrt_recipm1_acp;  // = -d mean / d out
                 for (int j = kLgWaves - 1 - w; j < Nn; j += kLgWaves) {
                     const float e = a.eps ? a.eps[row * Nn + j] : (FAST ? pf.normal(j) : pn.normal(j));
                     const float xs = xr[j];
                     const float xj = st.sqrt_acp * xs + st.sqrt_1m_acp * e;   // GMD:302, as k_q_sample forms it
-                    const float x0_hat = st.sqrt_recip_acp * xj - st.sqrt_recipm1_acp * mo[j * ld];
+                    const float x0_hat = a.d.gx0 ? mo[j * ld] : st.sqrt_recip_acp * xj - st.sqrt_recipm1_acp * mo[j * ld];
                     const float mean = c1 * x0_hat + c2 * xj;
                     double term, grad;
                     if (t != 0) {
@@ -1440,13 +1453,16 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 float sum = 0.0f;
                 MTK_LG_COLS(i) sum += ex<FAST>(MTK_LG_COL(i) - mx);
                 const float lsum = lg<FAST>(sum);
-                const float ev_top = (t == 0) ? -lsum : lae_t<FAST>(-lsum + s1.log_acp, ce);
-                const float m_m = ev_top + q_hot;
+                // Parametrization.DIRECT (GMD:828-829): the model side is the log-softmax itself (un = lsm, d un / d lsm = 1)
+                const bool direct = a.d.direct != 0, plain = (t == 0) || direct;
+                const float qm_hot = direct ? 0.0f : q_hot, qm_cold = direct ? 0.0f : q_cold;
+                const float ev_top = plain ? -lsum : lae_t<FAST>(-lsum + s1.log_acp, ce);
+                const float m_m = ev_top + qm_hot;
                 float b_m = 0.0f, acc_kl = 0.0f, un_c0 = 0.0f;
                 MTK_LG_COLS(i) {
                     const float lsm = (MTK_LG_COL(i) - mx) - lsum;
-                    const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
-                    const float un = ev + ((i == ct) ? q_hot : q_cold);
+                    const float ev = plain ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
+                    const float un = ev + ((i == ct) ? qm_hot : qm_cold);
                     b_m += ex<FAST>(un - m_m);
                     const float lt = (i == c0) ? lt_c0 : ((i == ct) ? lt_ct : lt_cc);
                     const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
@@ -1462,12 +1478,12 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
                 float G = 0.0f;
                 MTK_LG_COLS(i) {
                     const float lsm = (MTK_LG_COL(i) - mx) - lsum;
-                    const float ev = (t == 0) ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
-                    const float un = ev + ((i == ct) ? q_hot : q_cold);
+                    const float ev = plain ? lsm : lae_t<FAST>(lsm + s1.log_acp, ce);
+                    const float un = ev + ((i == ct) ? qm_hot : qm_cold);
                     const float p = ex<FAST>(un - lse_m);
                     const float w = (i == c0) ? w_c0 : ((i == ct) ? w_ct : w_cc);
                     const float gun = (t == 0) ? (p - ((i == c0) ? 1.0f : 0.0f)) : (p * w_sum - w);
-                    const float sl = (t == 0) ? 1.0f : ex<FAST>((lsm + s1.log_acp) - ev);
+                    const float sl = plain ? 1.0f : ex<FAST>((lsm + s1.log_acp) - ev);
                     const float gi = gun * sl;
                     G += gi;
                     if (KC > 0) gq[KC > 0 ? i : 0] = gi;
@@ -1504,7 +1520,7 @@ __global__ __launch_bounds__(64 * kLgWaves) void k_loss_grad(LossGradArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct KlArgs {
     int64_t B;
-    int Nn, T;
+    int Nn, T, gx0;
     const SchedRow* rows;
     const double* tab;  // [T][4]: posterior_mean_coef1, posterior_mean_coef2, posterior_log_variance_clipped, model log-variance
     const float* mo; int64_t mo_rs, mo_cs;
@@ -1536,7 +1552,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_kl_rows(KlArgs a) {
             for (int j = 0; j < a.Nn; ++j) {
                 const float xs = x0[j], xj = xt[j * a.xt_cs], ej = mo[j * a.mo_cs];
                 const float true_mean = c1 * xs + c2 * xj;
-                const float x0_hat = sr.sqrt_recip_acp * xj - sr.sqrt_recipm1_acp * ej;
+                const float x0_hat = a.gx0 ? ej : sr.sqrt_recip_acp * xj - sr.sqrt_recipm1_acp * ej;
                 const float mean = c1 * x0_hat + c2 * xj;
                 const float d = true_mean - mean;
                 acc += 0.5 * ((head + e1) + (double)(d * d) * e2);
@@ -1545,7 +1561,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_kl_rows(KlArgs a) {
             const double inv_stdv = exp(-(0.5 * lv2));
             for (int j = 0; j < a.Nn; ++j) {
                 const float xs = x0[j], xj = xt[j * a.xt_cs], ej = mo[j * a.mo_cs];
-                const float x0_hat = sr.sqrt_recip_acp * xj - sr.sqrt_recipm1_acp * ej;
+                const float x0_hat = a.gx0 ? ej : sr.sqrt_recip_acp * xj - sr.sqrt_recipm1_acp * ej;
                 const float mean = c1 * x0_hat + c2 * xj;
                 const float centered = xs - mean;
                 const double cdf_plus = approx_normal_cdf(inv_stdv * (double)(centered + (float)(1.0 / 255.0)));
@@ -1832,7 +1848,7 @@ extern "C" int mtk_ddim_reverse_step(mtk_ctx* ctx, int64_t B, int t, const float
     if (B == 0 || ctx->Nn == 0) return MTK_OK;
     MTK_HIP(hipSetDevice(ctx->device));
     DdimRevArgs a;
-    a.B = B; a.Nn = ctx->Nn;
+    a.B = B; a.Nn = ctx->Nn; a.gx0 = ctx->gauss_x0;
     a.sqrt_recip = (float)ctx->tab(MTK_TAB_SQRT_RECIP_ACP, t);
     a.sqrt_recipm1 = (float)ctx->tab(MTK_TAB_SQRT_RECIPM1_ACP, t);
     const float abn = t + 1 < ctx->T ? (float)ctx->tab(MTK_TAB_ACP, t + 1) : 0.0f;  // alphas_cumprod_next, GMD:262
@@ -1872,7 +1888,7 @@ extern "C" int mtk_gauss_kl_rows(mtk_ctx* ctx, int64_t B, const float* model_out
         const int rck = mtk_ensure_kl_tab(ctx);
         if (rck) return rck;
     }
-    KlArgs a{B, ctx->Nn, ctx->T, ctx->d_rows, ctx->d_kl, model_out, mo_rs, mo_cs, x0, x0_ld, x_t, xt_rs, xt_cs, t, loss};
+    KlArgs a{B, ctx->Nn, ctx->T, ctx->gauss_x0, ctx->d_rows, ctx->d_kl, model_out, mo_rs, mo_cs, x0, x0_ld, x_t, xt_rs, xt_cs, t, loss};
     hipLaunchKernelGGL(k_gauss_kl_rows, dim3(grid_for(B)), dim3(kBlock), 0, (hipStream_t)stream, a);
     MTK_HIP(hipGetLastError());
     return mtk_poison_bad_t(t, B, ctx->T, nullptr, 0, 0, 0, nullptr, 0, 0, 0, loss, (hipStream_t)stream);
@@ -1894,6 +1910,13 @@ extern "C" int mtk_sample_decode(mtk_ctx* ctx, int64_t B, const double* z, const
 extern "C" int mtk_ctx_set_seed_source(mtk_ctx* ctx, const uint64_t* seed_row0_dev) {
     if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_set_seed_source: null context");
     ctx->seed_src = seed_row0_dev;
+    return MTK_OK;
+}
+
+extern "C" int mtk_ctx_set_parametrization(mtk_ctx* ctx, int gaussian_x0, int multinomial_direct) {
+    if (!ctx) MTK_FAIL(MTK_ERR_ARG, "mtk_ctx_set_parametrization: null context");
+    ctx->gauss_x0 = gaussian_x0 != 0;
+    ctx->direct = multinomial_direct != 0;
     return MTK_OK;
 }
 

@@ -126,9 +126,9 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         # the reference raises ValueError lazily for these enums (GMD:408, 543, 832); do it up front
         if getattr(gaussian_loss_type, "value", None) not in ("mse", "kl"):
             raise ValueError(f"Unsupported Gaussian loss type: {gaussian_loss_type}")
-        if getattr(gaussian_parametrization, "value", None) != "eps":
+        if getattr(gaussian_parametrization, "value", None) not in ("eps", "x0"):
             raise ValueError(f"Unsupported Gaussian parametrization: {gaussian_parametrization}")
-        if getattr(parametrization, "value", None) != "x0":
+        if getattr(parametrization, "value", None) not in ("x0", "direct"):
             raise ValueError(f"Unsupported parametrization: {parametrization}")
         scheduler_type = SchedulerType(getattr(scheduler_type, "value", scheduler_type))
 
@@ -209,6 +209,9 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                 self._denoise_fn._synced_key = None  # the packed bf16 images do not follow a training image: detach and re-pack
             self._denoise_fn.sync_weights()
         self._engine.set_math(self.math or ("fast" if self.rng == "philox" else "reference"))
+        # GMD:399-408 / 822-832: what the denoiser's two output blocks mean (mtk_ctx_set_parametrization)
+        self._engine.set_parametrization(getattr(self.gaussian_parametrization, "value", self.gaussian_parametrization) == "x0",
+                                         getattr(self.parametrization, "value", self.parametrization) == "direct")
         return self._engine
 
     def _label_net(self) -> bool:
@@ -265,6 +268,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         key = (n, str(dev))
         if cache.get(key) is None:
             cache[key] = Engine(dev, self.num_timesteps, n, [0], self._host_tables)
+        cache[key].set_parametrization(getattr(self.gaussian_parametrization, "value", self.gaussian_parametrization) == "x0", False)
         return cache[key]
 
     # ------------------------------------------------------------------ loss entry point

@@ -69,6 +69,10 @@ class Engine:
         """"reference" (parity, default) or "fast" (hardware transcendentals, exact block log-sum-exp)."""
         check(_lib.lib().mtk_ctx_set_math(self._h, {"reference": 0, "fast": 1}[mode]))
 
+    def set_parametrization(self, gaussian_x0: bool, multinomial_direct: bool) -> None:
+        """GaussianParametrization.X0 / Parametrization.DIRECT of the reference's constructor (mtk_ctx_set_parametrization)."""
+        check(_lib.lib().mtk_ctx_set_parametrization(self._h, int(bool(gaussian_x0)), int(bool(multinomial_direct))))
+
     def reserve(self, max_rows: int) -> None:
         """Size every workspace for calls of up to ``max_rows`` rows: afterwards no entry point allocates or synchronises
         (needed before capturing calls into a HIP graph)."""

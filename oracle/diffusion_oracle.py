@@ -222,9 +222,11 @@ def model_input(x_num_t: torch.Tensor, xt_idx: torch.Tensor, K) -> torch.Tensor:
 
 
 def loss_rows(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0: torch.Tensor, xt_idx: torch.Tensor,
-              eps: torch.Tensor | None, t: torch.Tensor):
+              eps: torch.Tensor | None, t: torch.Tensor, direct: bool = False):
     """a9 + a10..a13 (GMD:984-1066) per record: (multinomial/C [B], gaussian [B]).
-    Degenerate sides return a 1-element zero tensor exactly like the reference."""
+    Degenerate sides return a 1-element zero tensor exactly like the reference.
+    ``direct``: Parametrization.DIRECT (GMD:828-829) - the model's reverse distribution is its per-block log-softmax, no posterior.
+    (The MSE Gaussian loss compares the output with the noise whatever the Gaussian parametrisation, GMD:531-532.)"""
     T = s.T
     lm = torch.zeros((1,), dtype=torch.float32)
     lg = torch.zeros((1,), dtype=torch.float32)
@@ -235,7 +237,7 @@ def loss_rows(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0: torch.Tensor
         lxt = log_onehot(xt_idx, K)
         out_cat = model_out[:, Nn:]
         true_p = q_posterior(s, lx0, lxt, t, K)
-        model_p = q_posterior(s, block_log_softmax(out_cat, K), lxt, t, K)
+        model_p = block_log_softmax(out_cat, K) if direct else q_posterior(s, block_log_softmax(out_cat, K), lxt, t, K)
         kl = (true_p.exp() * (true_p - model_p)).sum(dim=1)
         nll = -(lx0.exp() * model_p).sum(dim=1)
         mask = (t == 0).float()
@@ -332,15 +334,16 @@ def init_mlp_params(D: int, d_layers: list[int], dim_t: int = 128, seed: int = 0
     return p
 
 
-def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse", y=None, drop_masks=None, drop_p: float = 0.0):
+def mixed_loss(s: Schedule, K, Nn: int, params, x0, t, eps, u, gaussian_loss: str = "mse", y=None, drop_masks=None, drop_p: float = 0.0,
+               x0_param: bool = False, direct: bool = False):
     """a14 / GMD:1013 with injected (t, eps, u): returns per-record rows and the two means.  ``gaussian_loss = "kl"``:
     GaussianLossType.KL (GMD:534-541), the fp64 variational-bound term instead of the MSE.  ``y``: the labels GMD:1042 hands
     to a label-conditioned denoiser."""
     x_num_t, xt_idx = q_sample_fused(s, K, Nn, x0, t, eps, u)
     out = mlp_forward(params, model_input(x_num_t, xt_idx, K), t, y=y, drop_masks=drop_masks, drop_p=drop_p)
-    lm, lg = loss_rows(s, K, Nn, out, x0, xt_idx, eps, t)
+    lm, lg = loss_rows(s, K, Nn, out, x0, xt_idx, eps, t, direct)
     if gaussian_loss == "kl" and Nn > 0:
-        lg = gaussian_kl_rows(s, out[:, :Nn], x0[:, :Nn], x_num_t, t)
+        lg = gaussian_kl_rows(s, out[:, :Nn], x0[:, :Nn], x_num_t, t, x0_param)
     return lm, lg, lm.mean(), lg.mean()
 
 
@@ -358,14 +361,15 @@ def tf_score(s: Schedule, Nn: int, params, x: torch.Tensor, noise: torch.Tensor,
 
 # --------------------------------------------------------------------------- reverse chain (a16-a18)
 def gaussian_p_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor,
-                    grad: torch.Tensor | None = None):
+                    grad: torch.Tensor | None = None, x0_param: bool = False):
     """a16 / GMD:358-429, 663-705.  ``z`` is fp32 on the first step and fp64 afterwards (finding 0.4);
     dtype promotion is left to torch exactly as in the reference (per-row gathered, dimensioned
     coefficient tensors — a 0-dim fp64 coefficient would NOT promote an fp32 ``noise``).
     ``grad``: what the caller's conditioning function returned for ``z`` (condition_mean, GMD:585-615)."""
     tt = torch.full((z.shape[0],), t, dtype=torch.long)
     col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731  (DU:172 extract)
-    x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat
+    # GaussianParametrization.X0 (GMD:404-405): the output is pred_xstart itself
+    x0_hat = eps_hat if x0_param else col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat
     mean = col(s.posterior_mean_coef1) * x0_hat + col(s.posterior_mean_coef2) * z
     mask = (tt != 0).float().view(-1, 1)
     if grad is not None:  # GMD:614-615: the mean is cut to fp32, the fp64 variance promotes the sum again
@@ -373,15 +377,16 @@ def gaussian_p_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int,
     return mean + mask * torch.exp(0.5 * col(s.model_log_variance_f64)) * noise
 
 
-def multinomial_p_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tensor, t: int, u: torch.Tensor):
-    """a17 / GMD:810-871: posterior from the x0-parametrised logits, then Gumbel-argmax."""
+def multinomial_p_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Tensor, t: int, u: torch.Tensor, direct: bool = False):
+    """a17 / GMD:810-871: posterior from the x0-parametrised logits (or, Parametrization.DIRECT, the log-softmax itself), then Gumbel-argmax."""
     tt = torch.full((out_cat.shape[0],), t, dtype=torch.long)
-    logp = q_posterior(s, block_log_softmax(out_cat, K), log_onehot(z_idx, K), tt, K)
+    logp = block_log_softmax(out_cat, K) if direct else q_posterior(s, block_log_softmax(out_cat, K), log_onehot(z_idx, K), tt, K)
     return gumbel_argmax(logp, u, K)
 
 
 def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us,
-                 mlp_dtype: torch.dtype = torch.float32, conditioning_function=None, model_kwargs=None, y=None):
+                 mlp_dtype: torch.dtype = torch.float32, conditioning_function=None, model_kwargs=None, y=None, x0_param: bool = False,
+                 direct: bool = False):
     """a18 / GMD:1370-1424 with injected randomness (``y``: the drawn labels, GMD:1401, for a label-conditioned denoiser).  ``noises[i]``/``us[i]`` belong to the i-th
     executed step (t = T-1-i).  Returns [B, Nn+C] fp64 (numeric then category codes).
     ``conditioning_function(features, timestep, **model_kwargs)``: classifier guidance (GMD:699-702); with
@@ -396,9 +401,9 @@ def sample_chain(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Te
         tt = torch.full((B,), t, dtype=torch.long)
         out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype, y=y)
         grad = conditioning_function(z, tt, **(model_kwargs or {})) if conditioning_function is not None else None
-        z = gaussian_p_step(s, out[:, :Nn], z, t, noises[i], grad)
+        z = gaussian_p_step(s, out[:, :Nn], z, t, noises[i], grad, x0_param)
         if C:
-            z_idx = multinomial_p_step(s, K, out[:, Nn:], z_idx, t, us[i])
+            z_idx = multinomial_p_step(s, K, out[:, Nn:], z_idx, t, us[i], direct)
     return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z
 
 
@@ -436,12 +441,12 @@ def classifier_conditioning_function(state: dict[str, torch.Tensor], scale: floa
 
 # --------------------------------------------------------------------------- DDIM (section 8f rank 4)
 def gaussian_ddim_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, noise: torch.Tensor, eta: float = 0.0,
-                       cond_grad: torch.Tensor | None = None):
+                       cond_grad: torch.Tensor | None = None, x0_param: bool = False):
     """GMD:1070-1118: every table involved is fp32, so an fp32 state stays fp32.  ``cond_grad`` = what the conditioning
     function returned for (z, t): condition_score (GMD:617-661) then replaces the predicted x0."""
     tt = torch.full((z.shape[0],), t, dtype=torch.long)
     col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731
-    x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat  # GMD:545
+    x0_hat = eps_hat if x0_param else col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat  # GMD:399-405, 545
     ab, abp = col(s.alphas_cumprod), col(s.alphas_cumprod_prev)
     if cond_grad is not None:
         e = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)  # GMD:651
@@ -454,11 +459,11 @@ def gaussian_ddim_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: i
     return mean_pred + mask * sigma * noise
 
 
-def gaussian_ddim_reverse_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int):
+def gaussian_ddim_reverse_step(s: Schedule, eps_hat: torch.Tensor, z: torch.Tensor, t: int, x0_param: bool = False):
     """GMD:1160-1186."""
     tt = torch.full((z.shape[0],), t, dtype=torch.long)
     col = lambda tab: tab[tt][:, None].expand(z.shape)  # noqa: E731
-    x0_hat = col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat
+    x0_hat = eps_hat if x0_param else col(s.sqrt_recip_alphas_cumprod) * z - col(s.sqrt_recipm1_alphas_cumprod) * eps_hat
     eps = (col(s.sqrt_recip_alphas_cumprod) * z - x0_hat) / col(s.sqrt_recipm1_alphas_cumprod)
     abn = col(s.alphas_cumprod_next)
     return x0_hat * torch.sqrt(abn) + torch.sqrt(1 - abn) * eps
@@ -480,7 +485,7 @@ def multinomial_ddim_step(s: Schedule, K, out_cat: torch.Tensor, z_idx: torch.Te
 
 
 def sample_chain_ddim(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: torch.Tensor | None, noises, us,
-                      mlp_dtype: torch.dtype = torch.float32):
+                      mlp_dtype: torch.dtype = torch.float32, x0_param: bool = False):
     """sample_ddim (GMD:1259-1316) with injected randomness; returns [B, Nn+C] fp32."""
     C = 0 if (len(K) == 0 or int(K[0]) == 0) else len(K)
     z = z0
@@ -491,7 +496,7 @@ def sample_chain_ddim(s: Schedule, K, Nn: int, params, z0: torch.Tensor, u0: tor
     for i, t in enumerate(reversed(range(s.T))):
         tt = torch.full((B,), t, dtype=torch.long)
         out = mlp_forward(params, model_input(z.float(), z_idx, K) if C else z.float(), tt, dtype=mlp_dtype).float()
-        z = gaussian_ddim_step(s, out[:, :Nn], z, t, noises[i])
+        z = gaussian_ddim_step(s, out[:, :Nn], z, t, noises[i], x0_param=x0_param)
         if C:
             z_idx = multinomial_ddim_step(s, K, out[:, Nn:], z_idx, t, us[i])
     return torch.cat([z, z_idx.to(z.dtype)], dim=1) if C else z
@@ -530,12 +535,13 @@ def multinomial_loss_floor(s: Schedule, K, Nn: int, model_out: torch.Tensor, x0:
 
 # --------------------------------------------------------------------------- training (a19)
 def loss_and_grads(s: Schedule, K, Nn: int, params: dict[str, torch.Tensor], x0, t, eps, u, gaussian_loss: str = "mse", y=None,
-                   drop_masks=None, drop_p: float = 0.0):
+                   drop_masks=None, drop_p: float = 0.0, x0_param: bool = False, direct: bool = False):
     """TRAINER:88-91: ``zero_grad; loss_multi + loss_gauss; backward`` with injected (t, eps, u).
     Returns (grads by parameter name, loss_multi mean, loss_gauss mean).  The gradient is torch
     autograd through the restated forward ops, i.e. exactly what the reference differentiates."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u, gaussian_loss, y=y, drop_masks=drop_masks, drop_p=drop_p)
+    _, _, m_mean, g_mean = mixed_loss(s, K, Nn, leaf, x0, t, eps, u, gaussian_loss, y=y, drop_masks=drop_masks, drop_p=drop_p,
+                                      x0_param=x0_param, direct=direct)
     (m_mean + g_mean).backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
     return grads, m_mean.detach(), g_mean.detach()
@@ -620,7 +626,8 @@ def quantile_inverse(x: np.ndarray, quantiles: np.ndarray, references: np.ndarra
 
 
 # --------------------------------------------------------------------------- KL Gaussian loss (a9, gaussian_loss_type = KL)
-def gaussian_kl_rows(s: Schedule, model_out: torch.Tensor, x0: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+def gaussian_kl_rows(s: Schedule, model_out: torch.Tensor, x0: torch.Tensor, x_t: torch.Tensor, t: torch.Tensor,
+                     x0_param: bool = False) -> torch.Tensor:
     """``_gaussian_loss`` with ``GaussianLossType.KL`` (GMD:534-541 -> ``_vb_terms_bpd`` GMD:431-484, ``normal_kl`` DU:9-45,
     ``discretized_gaussian_log_likelihood`` DU:62-91, ``approx_standard_normal_cdf`` DU:48-59) for the EPS
     parametrisation.  Means and the clipped posterior log-variance are fp32, the model's log-variance row is fp64
@@ -629,7 +636,7 @@ def gaussian_kl_rows(s: Schedule, model_out: torch.Tensor, x0: torch.Tensor, x_t
     col = lambda tab: tab[t][:, None].expand(x_t.shape)  # noqa: E731  (DU:172 extract)
     true_mean = col(s.posterior_mean_coef1) * x0 + col(s.posterior_mean_coef2) * x_t
     lv1 = col(s.posterior_log_variance_clipped)
-    x0_hat = col(s.sqrt_recip_alphas_cumprod) * x_t - col(s.sqrt_recipm1_alphas_cumprod) * model_out
+    x0_hat = model_out if x0_param else col(s.sqrt_recip_alphas_cumprod) * x_t - col(s.sqrt_recipm1_alphas_cumprod) * model_out  # GMD:399-405
     mean = col(s.posterior_mean_coef1) * x0_hat + col(s.posterior_mean_coef2) * x_t
     lv2 = col(s.model_log_variance_f64)
     kl = 0.5 * (-1.0 + lv2 - lv1 + torch.exp(lv1 - lv2) + ((true_mean - mean) ** 2) * torch.exp(-lv2))

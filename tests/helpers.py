@@ -10,6 +10,13 @@ from oracle import diffusion_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["A_numeric", "B_ragged", "M_mixed", "N_tf", "L_catonly", "K1_single"]
+# fixtures generated from the reference constructed with GaussianParametrization.X0 / Parametrization.DIRECT (make_golden.py --param-only):
+# tag -> the oracle's flags
+PARAM_FLAGS = {"P_x0direct": {"x0_param": True, "direct": True}}
+
+
+def oracle_flags(c: dict) -> dict:
+    return dict(PARAM_FLAGS.get(c.get("tag", ""), {}))
 
 
 def load_case(tag: str) -> dict:
@@ -23,6 +30,7 @@ def load_case(tag: str) -> dict:
     d["C"] = len(d["K"]) if int(d["K"][0]) != 0 else 0
     d["S"] = int(d["K"].sum())
     d["D"] = d["Nn"] + d["S"]
+    d["tag"] = tag
     return d
 
 
@@ -70,6 +78,7 @@ def load_ddim(tag: str) -> dict:
     d["C"] = len(d["K"]) if int(d["K"][0]) != 0 else 0
     d["S"] = int(d["K"].sum())
     d["D"] = d["Nn"] + d["S"]
+    d["tag"] = tag
     return d
 
 

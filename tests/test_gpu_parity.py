@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from oracle import diffusion_oracle as orc
-from tests.helpers import CASES, case_params, load_case, tt
+from tests.helpers import CASES, case_params, load_case, oracle_flags, tt
 
 pytestmark = pytest.mark.gpu
 TIE_MARGIN = 2e-5
@@ -34,8 +34,11 @@ def build(c, precision="fp32", T=None):
     net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, dp)
     net.load_state_dict(case_params(c), strict=True)
     net.precision = precision
+    fl = oracle_flags(c)  # fixtures of the X0 / DIRECT parametrisations build the drop-in the way the reference was built
     d = mtk.GaussianMultinomialDiffusion(c["K"], c["Nn"], net, num_timesteps=T or c["T"],
-                                         scheduler_type=mtk.SchedulerType(c["sched"]), device=dev())
+                                         scheduler_type=mtk.SchedulerType(c["sched"]), device=dev(),
+                                         gaussian_parametrization=mtk.GaussianParametrization.X0 if fl.get("x0_param") else mtk.GaussianParametrization.EPS,
+                                         parametrization=mtk.Parametrization.DIRECT if fl.get("direct") else mtk.Parametrization.X0)
     d = d.to(dev())
     d.precision = precision
     return d
@@ -174,7 +177,7 @@ def test_mlp_forward_fp32(tag):
     close(o3, orc.mlp_forward(case_params(c), tt(c["ml_model_in"]), tv), rtol=RTOL, atol=1e-5 * scale)
 
 
-@pytest.mark.parametrize("tag", CASES)
+@pytest.mark.parametrize("tag", CASES + ["P_x0direct"])
 def test_loss_rows_with_injected_model_out(tag):
     c = load_case(tag)
     d = build(c)
@@ -200,7 +203,7 @@ def test_loss_rows_with_injected_model_out(tag):
         assert int(tt(c["ml_t"])[0]) == 0 and bool(torch.isfinite(lm[0].cpu()))
 
 
-@pytest.mark.parametrize("tag", CASES)
+@pytest.mark.parametrize("tag", CASES + ["P_x0direct"])
 def test_mixed_loss_end_to_end(tag):
     c = load_case(tag)
     d = build(c)
@@ -248,7 +251,7 @@ def test_tf_score_fp32(tag):
         close(many[j], tt(c[f"tf{k}_score"]), rtol=RTOL)
 
 
-@pytest.mark.parametrize("tag", CASES)
+@pytest.mark.parametrize("tag", CASES + ["P_x0direct"])
 def test_reverse_steps(tag):
     c = load_case(tag)
     d = build(c)
@@ -273,7 +276,7 @@ def test_reverse_steps(tag):
             assert torch.equal(x_next[Nn:].t().cpu(), want_oh)
 
 
-@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly", "K1_single"])
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "L_catonly", "K1_single", "P_x0direct"])
 def test_full_chain(tag):
     c = load_case(tag)
     Tc = int(c["ch_T"])
@@ -301,10 +304,35 @@ def test_full_chain(tag):
         cpu = lambda v: v.cpu() if isinstance(v, torch.Tensor) else v  # noqa: E731
         args = (s, c["K"], Nn, case_params(c), cpu(inj["z0"]), cpu(inj.get("u0")), [cpu(n) for n in noise],
                 [cpu(v) for v in inj["u"]] if C else [None] * len(noise))
-        ref64 = orc.sample_chain(*args, mlp_dtype=torch.float64)
+        ref64 = orc.sample_chain(*args, mlp_dtype=torch.float64, **oracle_flags(c))
         agree = same & ((ref64[:, Nn:] == want[:, Nn:]).all(dim=1) if C else same)
         own = float((ref64[agree][:, :Nn] - want[agree][:, :Nn]).abs().max())
         close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=max(1e-5, 3 * own))
+
+
+def test_reverse_ddim_step_x0_parametrisation():
+    """gaussian_ddim_reverse_step (GMD:1160-1186) with GaussianParametrization.X0 (the denoiser output is pred_xstart, GMD:404-405):
+    single steps with injected denoiser output against the reference's (tests/golden/ddimrev_P_x0direct.npz); with the default
+    parametrisation the same inputs give another state."""
+    import os
+
+    import midst_toolkit_amd as mtk
+
+    r = np.load(os.path.join(os.path.dirname(__file__), "golden", "ddimrev_P_x0direct.npz"))
+    Nn, T = int(r["Nn"]), int(r["T"])
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([int(v) for v in r["d_layers"]], 0.0))
+    for x0_param in (True, False):
+        d = mtk.GaussianMultinomialDiffusion(np.array([0]), Nn, net, num_timesteps=T, device=dev(),
+                                             gaussian_parametrization=mtk.GaussianParametrization.X0 if x0_param else mtk.GaussianParametrization.EPS).to(dev())
+        eng = d.engine()
+        for k in range(3):
+            z = tt(r[f"r{k}_z"]).double().t().contiguous().to(dev())
+            B = z.shape[1]
+            eng.ddim_reverse_step(B, int(r[f"r{k}_t"]), colmajor(tt(r[f"r{k}_model_out"])), (1, B), z, None, (1, B))
+            if x0_param:
+                close(z.t(), tt(r[f"r{k}_z_new"]), rtol=1e-6, atol=1e-6)
+            else:
+                assert float((z.t().cpu() - tt(r[f"r{k}_z_new"]).double()).abs().max()) > 1e-2
 
 
 @pytest.mark.parametrize("which", ["cs", "sg"])
@@ -355,7 +383,7 @@ def test_guided_chains(which):
     assert float((plain - want).abs().max()) > 1e-2
 
 
-@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged"])
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "P_x0direct"])
 def test_ddim_chain(tag):
     """sample_ddim (GMD:1259, eta = 0) with the reference's draws injected against the reference's output
     (tests/golden/ddim_*.npz; the oracle reproduces it bit for bit): the whole-chain bar of test_full_chain."""
@@ -376,7 +404,7 @@ def test_ddim_chain(tag):
     s = orc.make_schedule(T, c["sched"])
     us = [tt(v) for v in c["u"]] if C else [None] * T
     ref64 = orc.sample_chain_ddim(s, c["K"], Nn, case_params(c), tt(c["z0"]), tt(c["u0"]) if C else None, [tt(n) for n in c["noise"]], us,
-                                  mlp_dtype=torch.float64)
+                                  mlp_dtype=torch.float64, x0_param=oracle_flags(c).get("x0_param", False))
     agree = same & ((ref64[:, Nn:] == want[:, Nn:]).all(dim=1) if C else same)
     own = float((ref64[agree][:, :Nn] - want[agree][:, :Nn]).abs().max())
     close(got[same][:, :Nn], want[same][:, :Nn], rtol=RTOL, atol=max(1e-5, 3 * own))
@@ -1318,7 +1346,7 @@ def _big_mixed_batch(c, B, seed=11):
     return x0, t, torch.randn((B, Nn), generator=g), torch.rand((B, S), generator=g)
 
 
-@pytest.mark.parametrize("tag", ["M_mixed", "B_ragged", "K1_single"])
+@pytest.mark.parametrize("tag", ["M_mixed", "B_ragged", "K1_single", "P_x0direct"])
 def test_fast_math_against_oracle(tag, monkeypatch):
     global TIE_MARGIN
     c = load_case(tag)
@@ -1338,7 +1366,8 @@ def test_fast_math_against_oracle(tag, monkeypatch):
     check_categorical(idx.t(), want_idx, logits, u, c["K"])
     # loss with the oracle's denoiser output and categories injected
     out = orc.mlp_forward(case_params(c), orc.model_input(want_xt, want_idx, c["K"]), t)
-    wm, wg = orc.loss_rows(s, c["K"], Nn, out, x0, want_idx, eps, t)
+    fl = oracle_flags(c)
+    wm, wg = orc.loss_rows(s, c["K"], Nn, out, x0, want_idx, eps, t, direct=fl.get("direct", False))
     lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
     eng.loss_rows(colmajor(out), (1, B), x0.to(dev()), want_idx.t().contiguous().int().to(dev()), eps.to(dev()), t.to(dev()), lm, lg)
     close(lg, wg, rtol=1e-5)
@@ -1355,9 +1384,11 @@ def test_fast_math_against_oracle(tag, monkeypatch):
         zi = torch.stack([torch.randint(0, int(k), (B,), generator=g) for k in c["K"]], 1)
         n = torch.randn((B, Nn), generator=g, dtype=torch.float64)
         uu = torch.rand((B, c["S"]), generator=g)
-        want_z = orc.gaussian_p_step(s, mo[:, :Nn], z, tt_, n)
+        want_z = orc.gaussian_p_step(s, mo[:, :Nn], z, tt_, n, x0_param=fl.get("x0_param", False))
         tv = torch.full((B,), tt_, dtype=torch.long)
         logp = orc.q_posterior(s, orc.block_log_softmax(mo[:, Nn:], c["K"]), orc.log_onehot(zi, c["K"]), tv, c["K"])
+        if fl.get("direct"):
+            logp = orc.block_log_softmax(mo[:, Nn:], c["K"])
         want_zi = orc.gumbel_argmax(logp, uu, c["K"])
         zd = z.t().contiguous().to(dev())
         zid = zi.t().contiguous().int().to(dev())
@@ -1366,7 +1397,7 @@ def test_fast_math_against_oracle(tag, monkeypatch):
         check_categorical(zid.t(), want_zi, logp, uu, c["K"])
 
 
-@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed"])
+@pytest.mark.parametrize("tag", ["A_numeric", "B_ragged", "M_mixed", "P_x0direct"])
 def test_gaussian_kl_loss(tag):
     """GaussianLossType.KL through the C ABI (mtk_gauss_kl_rows) against the reference's own per-record values
     (tests/golden/kl_*.npz; the oracle equals them bit for bit): fp64 arithmetic on both sides, 1e-4 relative is the

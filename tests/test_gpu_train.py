@@ -158,6 +158,52 @@ def test_kl_gaussian_loss_gradients(tag):
         assert num <= 3e-4 * den + 3 * floor[k] + 1e-9, f"autograd {k}: relative L2 error {num / max(den, 1e-30):.3e}"
 
 
+@pytest.mark.parametrize("gaussian_loss", ["mse", "kl"])
+@pytest.mark.parametrize("math", ["reference", "fast"])
+def test_x0_and_direct_parametrisations_train(gaussian_loss, math):
+    """GaussianParametrization.X0 + Parametrization.DIRECT (GMD:399-408, 822-832) in the training iteration: losses and every
+    gradient tensor against the oracle's autograd through its restatement of both branches (bit-exact against the reference's own
+    fixtures, tests/test_oracle_golden.py).  DIRECT: d KL / d logits through the plain log-softmax; X0 with the KL Gaussian loss:
+    d mean / d output = posterior_mean_coef1 (with the MSE loss the Gaussian parametrisation does not enter, GMD:531-532).  Both
+    math modes of the loss-gradient kernel; bar as in test_kl_gaussian_loss_gradients (the reference's own movement under a 1e-7
+    weight perturbation is measured and allowed three times over)."""
+    import midst_toolkit_amd as mtk
+
+    c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[128, 128])
+    p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+    B = 768
+    x0, t, eps, u = big_batch(c, B)
+    t[:150] = 0
+    x0[:40, 0], x0[40:80, 1] = -1.5, 1.5
+    s = orc.make_schedule(c["T"], "cosine")
+    kw = dict(gaussian_loss=gaussian_loss, x0_param=True, direct=True)
+    want, lm_ref, lg_ref = orc.loss_and_grads(s, c["K"], c["Nn"], p0, x0, t, eps, u, **kw)
+    g7 = torch.Generator().manual_seed(0)
+    p1 = {k: (v * (1 + 1e-7 * torch.randn(v.shape, generator=g7))).float() for k, v in p0.items()}
+    moved, _, _ = orc.loss_and_grads(s, c["K"], c["Nn"], p1, x0, t, eps, u, **kw)
+    floor = {k: float((moved[k].double() - want[k].double()).norm()) for k in want}
+    net = mtk.MLPDiffusion(c["D"], 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(c["d_layers"]), 0.0))
+    net.load_state_dict(p0, strict=True)
+    d = mtk.GaussianMultinomialDiffusion(np.asarray(c["K"]), c["Nn"], net, num_timesteps=c["T"], device=dev(),
+                                         gaussian_loss_type=mtk.GaussianLossType(gaussian_loss),
+                                         gaussian_parametrization=mtk.GaussianParametrization.X0, parametrization=mtk.Parametrization.DIRECT).to(dev())
+    d.math = math
+    tr = mtk.ClavaDDPMTrainer(d, iter(()), 2e-3, 1e-4, 12, device=dev())
+    eng = tr._engine
+    eng.train_set_gaussian_loss(gaussian_loss)
+    eng.set_math(math)
+    lm, lg = torch.empty(B, device=dev()), torch.empty(B, device=dev())
+    eng.train_step(x0.to(dev()), t.to(dev()), eps.to(dev()), u.to(dev()), 1.0 / B, lm, lg)
+    got = export(tr, "grads")
+    assert abs(float(lm.mean()) - float(lm_ref)) <= 2e-4 * abs(float(lm_ref)) and abs(float(lg.mean()) - float(lg_ref)) <= 2e-4 * abs(float(lg_ref))
+    for k in want:
+        num, den = float((got[k].double() - want[k].double()).norm()), float(want[k].double().norm())
+        assert num <= 4e-4 * den + 3 * floor[k] + 1e-9, f"{k}: relative L2 error {num / max(den, 1e-30):.3e} (floor {floor[k] / max(den, 1e-30):.3e})"
+    # the flags do something: the default parametrisations give other gradients on the same batch
+    other, _, _ = orc.loss_and_grads(s, c["K"], c["Nn"], p0, x0, t, eps, u, gaussian_loss=gaussian_loss)
+    assert float((other["mlp.head.weight"] - want["mlp.head.weight"]).norm()) > 1e-2 * float(want["mlp.head.weight"].norm())
+
+
 @pytest.mark.parametrize("B,layers", [(4096, [512] * 4), (2048, [1024] * 4), (1000, [256, 128, 256])])
 def test_bf16_training_gradients(B, layers):
     """mtk_train_set_precision(MTK_PREC_BF16): every GEMM of the iteration multiplies bf16-rounded operands with fp32 accumulation

@@ -69,10 +69,14 @@ def test_unsupported_enums_raise_value_error():
     assert kl.gaussian_loss_type is mtk.GaussianLossType.KL  # both loss types of GMD:531-543 are served
     with pytest.raises(ValueError):
         mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_loss_type="huber", device=torch.device("cpu"))
+    # both values of both parametrisation enums are served since round 3 (GMD:399-408, 822-832); anything else raises as the reference does
+    alt = mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_parametrization=mtk.GaussianParametrization.X0,
+                                           parametrization=mtk.Parametrization.DIRECT, device=torch.device("cpu"))
+    assert alt.gaussian_parametrization is mtk.GaussianParametrization.X0 and alt.parametrization is mtk.Parametrization.DIRECT
     with pytest.raises(ValueError):
-        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_parametrization=mtk.GaussianParametrization.X0, device=torch.device("cpu"))
+        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, gaussian_parametrization="v", device=torch.device("cpu"))
     with pytest.raises(ValueError):
-        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, parametrization=mtk.Parametrization.DIRECT, device=torch.device("cpu"))
+        mtk.GaussianMultinomialDiffusion(np.array([0]), 4, net, parametrization="logits", device=torch.device("cpu"))
 
 
 def test_library_exports_every_declared_symbol():

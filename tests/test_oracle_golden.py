@@ -292,3 +292,57 @@ def test_label_conditioned_denoiser_restatement():
     want = tt(c["ch_sample"])
     assert torch.equal(got[:, Nn:], want[:, Nn:])
     same(got[:, :Nn], want[:, :Nn], 1e-4)
+
+
+def test_x0_and_direct_parametrisations_bit_exact():
+    """GaussianParametrization.X0 + Parametrization.DIRECT (GMD:399-408, 822-832): the oracle's branches against the reference
+    constructed with both (tools/make_golden.py --param-only) - mixed_loss rows and the whole call's means, single reverse steps
+    (numeric state, the reference's p_pred rows, the drawn codes), a whole ancestral chain, the KL Gaussian loss, a DDIM chain and
+    reverse-DDIM steps: bit for bit.  The same checks with the default flags must FAIL on these fixtures (the flags do something)."""
+    import os
+
+    from tests.helpers import load_ddim
+
+    c = load_case("P_x0direct")
+    K, Nn = c["K"], c["Nn"]
+    s = orc.make_schedule(c["T"], c["sched"])
+    p = case_params(c)
+    x0, t, eps, u = tt(c["x0"]), tt(c["ml_t"]), tt(c["ml_eps"]), tt(c["ml_u"])
+    out, xt_idx = tt(c["ml_model_out"]), tt(c["ml_xt_idx"])
+    lm, lg = orc.loss_rows(s, K, Nn, out, x0, xt_idx, eps, t, direct=True)
+    assert torch.equal(lm, tt(c["ml_lm_rows"])) and torch.equal(lg, tt(c["ml_lg_rows"]))
+    assert not torch.equal(orc.loss_rows(s, K, Nn, out, x0, xt_idx, eps, t)[0], tt(c["ml_lm_rows"]))
+    _, _, m_mean, g_mean = orc.mixed_loss(s, K, Nn, p, x0, tt(c["ml_ref_call_t"]), eps, u, x0_param=True, direct=True)
+    assert np.float32(m_mean) == c["ml_ref_call_means"][0] and np.float32(g_mean) == c["ml_ref_call_means"][1]
+    for k in range(4):
+        tk = int(c[f"rs{k}_t"])
+        mo = tt(c[f"rs{k}_model_out"])
+        z_new = orc.gaussian_p_step(s, mo[:, :Nn], tt(c[f"rs{k}_z"]), tk, tt(c[f"rs{k}_n"]), x0_param=True)
+        assert z_new.dtype == torch.float64 and torch.equal(z_new, tt(c[f"rs{k}_z_new"])), (k, tk)
+        assert not torch.equal(orc.gaussian_p_step(s, mo[:, :Nn], tt(c[f"rs{k}_z"]), tk, tt(c[f"rs{k}_n"])), z_new)
+        idx = orc.multinomial_p_step(s, K, mo[:, Nn:], tt(c[f"rs{k}_z_idx"]), tk, tt(c[f"rs{k}_u"]), direct=True)
+        assert torch.equal(idx, tt(c[f"rs{k}_z_idx_new"])), (k, tk)
+        assert torch.equal(orc.block_log_softmax(mo[:, Nn:], K), tt(c[f"rs{k}_logp"]))
+    s2 = orc.make_schedule(int(c["ch_T"]), c["sched"])
+    noises = [tt(n) for n in c["ch_noise"]]
+    noises[0] = noises[0].float()
+    got = orc.sample_chain(s2, K, Nn, p, tt(c["ch_z0"]), tt(c["ch_u0"]), noises, [tt(v) for v in c["ch_u"]], x0_param=True, direct=True)
+    assert got.dtype == torch.float64 and torch.equal(got, tt(c["ch_sample"]))
+    # KL Gaussian loss
+    kf = np.load(os.path.join(os.path.dirname(__file__), "golden", "kl_P_x0direct.npz"))
+    mo, xt = out[:, :Nn], tt(c["ml_x_num_t"])
+    for name, tv in (("t", t), ("t0", torch.zeros_like(t)), ("t1", torch.ones_like(t))):
+        gk = orc.gaussian_kl_rows(s, mo, x0[:, :Nn], xt, tv, x0_param=True)
+        assert gk.dtype == torch.float64 and torch.equal(gk, torch.from_numpy(kf[f"kl_rows_{name}"])), name
+    assert not torch.equal(orc.gaussian_kl_rows(s, mo, x0[:, :Nn], xt, t), torch.from_numpy(kf["kl_rows_t"]))
+    # DDIM chain (the multinomial DDIM step has no parametrisation: GMD:1211-1257 reads the log-softmax directly) and reverse DDIM
+    d = load_ddim("P_x0direct")
+    sd = orc.make_schedule(d["T"], d["sched"])
+    gd = orc.sample_chain_ddim(sd, d["K"], d["Nn"], case_params(d), tt(d["z0"]), tt(d["u0"]), [tt(n) for n in d["noise"]], [tt(v) for v in d["u"]],
+                               x0_param=True)
+    assert gd.dtype == torch.float32 and torch.equal(gd, tt(d["sample"]))
+    r = np.load(os.path.join(os.path.dirname(__file__), "golden", "ddimrev_P_x0direct.npz"))
+    sr = orc.make_schedule(int(r["T"]), "cosine")
+    for k in range(3):
+        zn = orc.gaussian_ddim_reverse_step(sr, tt(r[f"r{k}_model_out"]), tt(r[f"r{k}_z"]), int(r[f"r{k}_t"]), x0_param=True)
+        assert torch.equal(zn, tt(r[f"r{k}_z_new"])), k

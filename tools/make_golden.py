@@ -57,6 +57,10 @@ def capture_rng(log: list):
             setattr(torch, n, saved[n])
 
 
+# extra constructor arguments of every diffusion built below (gen_parametrizations: the X0 / DIRECT variants, GMD:164-165)
+DIFF_KW: dict = {}
+
+
 def build(K, Nn, d_layers, T, sched="cosine", seed=0):
     K = np.asarray(K, dtype=np.int64)
     D = Nn + int(K.sum())
@@ -66,7 +70,7 @@ def build(K, Nn, d_layers, T, sched="cosine", seed=0):
     net.load_state_dict(params, strict=True)
     net.eval()
     st = gmd.SchedulerType.COSINE if sched == "cosine" else gmd.SchedulerType.LINEAR
-    diff = gmd.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, scheduler_type=st, device=CPU)
+    diff = gmd.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, scheduler_type=st, device=CPU, **DIFF_KW)
     diff.eval()
     return diff, params
 
@@ -450,6 +454,36 @@ def gen_classifier(tag="A_numeric", Nn=8, d_layers=(64, 64), T_chain=12, B=48, n
     print(f"classifier {tag}: logits {tuple(logits.shape)} |grad| {float(grad.abs().mean()):.3e} sample {tuple(smp.shape)}")
 
 
+def gen_parametrizations():
+    """GaussianParametrization.X0 and Parametrization.DIRECT (GMD:399-408, 822-832; no reference config uses them): the same
+    fixtures as for the defaults, from the reference constructed with both - a case file (mixed_loss rows, single reverse steps
+    with the reference's p_pred, a whole chain), the KL Gaussian loss on that case, and a DDIM chain."""
+    DIFF_KW.update(gaussian_parametrization=gmd.GaussianParametrization.X0, parametrization=gmd.Parametrization.DIRECT)
+    try:
+        gen_case("P_x0direct", [3, 7, 10, 2, 12], 6, [128, 128], 1000, 96, T_chain=16)
+        gen_kl("P_x0direct")
+        gen_ddim("P_x0direct", [3, 7, 10, 2, 12], 6, [128, 128], 16, 64)
+        gen_ddim_reverse("P_x0direct", 6, [64, 64], 12, 48)
+    finally:
+        DIFF_KW.clear()
+
+
+def gen_ddim_reverse(tag, Nn, d_layers, T, B):
+    """gaussian_ddim_reverse_step (GMD:1160-1186) at a few timesteps with injected denoiser output."""
+    diff, _ = build([0], Nn, d_layers, T)
+    g = torch.Generator().manual_seed(31)
+    out = {"Nn": np.array(Nn), "T": np.array(T), "d_layers": np.array(d_layers)}
+    for k, tt in enumerate([0, T // 2, T - 1]):
+        z = torch.randn((B, Nn), generator=g)
+        mo = torch.randn((B, Nn), generator=g)
+        with torch.no_grad():
+            zn = diff.gaussian_ddim_reverse_step(mo, z, torch.full((B,), tt, dtype=torch.long))
+        out[f"r{k}_t"] = np.array(tt)
+        out[f"r{k}_z"], out[f"r{k}_model_out"], out[f"r{k}_z_new"] = z.numpy(), mo.numpy(), zn.numpy()
+    np.savez_compressed(os.path.join(OUT, f"ddimrev_{tag}.npz"), **out)
+    print(f"ddimrev {tag}: B={B}")
+
+
 def gen_ddim(tag, K, Nn, d_layers, T_chain, B, sched="cosine"):
     """sample_ddim (GMD:1259) of the reference with every draw captured."""
     K = np.asarray(K, dtype=np.int64)
@@ -719,7 +753,7 @@ def gen_quantile():
         print(f"quantile {tag}: n_quantiles={qt.n_quantiles_} columns={train.shape[1]}")
 
 
-def gen_kl(tag):
+def gen_kl(tag, out_tag=None):
     """The KL Gaussian loss (gaussian_loss_type=KL: GMD:431-484 _vb_terms_bpd, DU:9-91) on the inputs the case fixture
     already holds (x0, t, x_t, model_out of the reference's own mixed_loss replay): per-record values for the stored t,
     for t = 0 everywhere (decoder NLL) and t = 1 everywhere, and the two means of a whole mixed_loss call."""
@@ -747,8 +781,8 @@ def gen_kl(tag):
     out["call_eps"] = log[1][1].numpy()
     out["call_means"] = np.array([float(m_mean), float(g_mean)], dtype=np.float64)
     out["call_gauss_dtype"] = np.array(str(g_mean.dtype))
-    np.savez_compressed(os.path.join(OUT, f"kl_{tag}.npz"), **out)
-    print(f"kl {tag}: rows dtype float64, mixed_loss gauss mean {float(g_mean):.6g} ({g_mean.dtype})")
+    np.savez_compressed(os.path.join(OUT, f"kl_{out_tag or tag}.npz"), **out)
+    print(f"kl {out_tag or tag}: rows dtype float64, mixed_loss gauss mean {float(g_mean):.6g} ({g_mean.dtype})")
 
 
 def gen_affine():
@@ -777,6 +811,9 @@ def gen_affine():
 def main():
     if "--affine-only" in sys.argv:
         gen_affine()
+        return
+    if "--param-only" in sys.argv:
+        gen_parametrizations()
         return
     if "--kl-only" in sys.argv:
         for tag in ("A_numeric", "B_ragged", "M_mixed"):
@@ -824,6 +861,7 @@ def main():
         gen_ddim_family()
         gen_edm()
         gen_label_embedding()
+        gen_parametrizations()
     # training: 12 iterations of the reference trainer, mixed and numeric-only shapes
     gen_train("B_ragged", [3, 7, 10, 2, 12], 6, [64, 64], 1000, 24, 12, 2e-3, 1e-4)
     gen_train("A_numeric", [0], 8, [64, 64], 100, 24, 12, 2e-3, 0.0)
