@@ -138,16 +138,18 @@ class ClavaDDPMTrainer:
         defer = self._exchange is None
         if defer:
             eng.train_set_deferred_reduce(True)
-        eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
-        eng.train_set_loss_means(None)
-        if self._exchange is not None:  # the one exchange of an iteration, bucket by bucket under the backward
-            self._exchange.launch()
-            self._exchange.wait()
-        g = self.optimizer.param_groups[0]
-        self.optimizer.steps_done += 1
-        eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
-        if defer:
-            eng.train_set_deferred_reduce(False)
+        try:
+            eng.train_step(x0, t, eps, u, 1.0 / (B * self._world), lm, lg, seed=seed, row0=self._rank * B)
+            eng.train_set_loss_means(None)
+            if self._exchange is not None:  # the one exchange of an iteration, bucket by bucket under the backward
+                self._exchange.launch()
+                self._exchange.wait()
+            g = self.optimizer.param_groups[0]
+            self.optimizer.steps_done += 1
+            eng.train_apply(g["lr"], g["weight_decay"], self.optimizer.steps_done, g["betas"], g["eps"], self.ema_rate)
+        finally:
+            if defer:  # also after an error: a later direct engine call must find the default mode (and a complete gradient image)
+                eng.train_set_deferred_reduce(False)
         return means[0], means[1]
 
     # ------------------------------------------------------------------ TRAINER:96
