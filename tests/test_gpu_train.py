@@ -1005,6 +1005,88 @@ def test_rccl_paths_on_a_single_rank_group():
     assert res["sampling"] == ((301, 11), True, True, True), res
 
 
+def _rccl_two_device_body(rank, ws, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK=str(rank), WORLD_SIZE=str(ws))
+    torch.cuda.set_device(rank)
+    mine = torch.device("cuda", rank)
+    globals()["dev"] = lambda: mine  # the helpers of this module build on dev(): this process works on its own GPU
+    dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=mine)
+    try:
+        import midst_toolkit_amd.distributed as D
+
+        c = dict(K=[3, 7, 10, 2, 12], Nn=6, T=1000, D=40, d_layers=[256, 128, 128])
+        p0 = orc.init_mlp_params(c["D"], c["d_layers"], seed=0)
+        B = 2048
+        lo, hi = D.shard_range(B, rank, ws)
+        batches = [[v[lo:hi].contiguous().to(mine) for v in big_batch(c, B, seed=10 + i)] for i in range(6)]
+
+        def run(mode):
+            tr, _ = build_trainer(c, p0, steps=len(batches))
+            assert (tr._rank, tr._world) == (rank, ws)
+            if mode == "overlapped":
+                assert tr._exchange.overlapped and not tr._exchange.forced and tr._exchange.stream is not None
+            elif mode == "buckets":
+                tr.use_exchange(False)
+            else:  # one blocking all-reduce of the whole gradient image (distributed.allreduce_gradients)
+                tr._exchange.close()
+                tr._exchange = None
+            snaps = []
+            for i, (x0, t, eps, u) in enumerate(batches):
+                if mode == "whole":
+                    tr._engine.train_step(x0, t, eps, u, 1.0 / B, None, None)
+                    D.allreduce_gradients(tr.state[1])
+                    g = tr.optimizer.param_groups[0]
+                    tr.optimizer.steps_done += 1
+                    tr._engine.train_apply(g["lr"], g["weight_decay"], tr.optimizer.steps_done, g["betas"], g["eps"], tr.ema_rate)
+                else:
+                    tr._train_step(x0, injected=(t, eps, u))
+                tr._anneal_learning_rate(i)
+                snaps.append((tr.state[1].clone(), tr.state[0].clone()))
+            torch.cuda.synchronize()
+            if tr._exchange is not None:
+                tr._exchange.close()
+            return snaps
+
+        whole, buckets, over = run("whole"), run("buckets"), run("overlapped")
+        same = lambda a, b: all(bool(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])) for x, y in zip(a, b))  # noqa: E731
+        q.put((rank, dict(buckets=same(whole, buckets), overlapped=same(whole, over), moved=not bool(torch.equal(whole[0][1], whole[-1][1])),
+                          weights=float(over[-1][1].double().sum()))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL between devices)")
+def test_rccl_gradient_exchange_between_two_devices():
+    """the overlapped exchange (side stream, per-bucket wait_event + all_reduce under the backward) between two GPUs
+    over RCCL, six consecutive iterations: gradient image and weights after every AdamW step bit-identical to the blocking
+    per-bucket form and to one all-reduce of the whole image, and identical on both ranks.  Skipped on a one-GPU box (there
+    test_rccl_paths_on_a_single_rank_group runs the same calls at world size 1)."""
+    import os
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_rccl_two_device_body, args=(r, 2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0, p.exitcode
+    res = dict(q.get() for _ in range(2))
+    for r in (0, 1):
+        assert res[r]["buckets"] and res[r]["overlapped"] and res[r]["moved"], res
+    assert res[0]["weights"] == res[1]["weights"], res
+
+
 def test_autograd_seam_leaves_a_trainers_image_alone():
     """A differentiable mixed_loss between trainer steps (a validation loss computed without torch.no_grad(), as loops written
     for the reference do) shares the trainer's context.  It must evaluate the LIVE weights of image 0 and never import the
