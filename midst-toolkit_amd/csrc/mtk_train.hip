@@ -1998,6 +1998,7 @@ extern "C" int mtk_train_import(mtk_ctx* c, int image, const float* const* W, co
     MTK_HIP(hipSetDevice(c->device));
     TrainState& tr = c->train;
     float* img = tr.state + (size_t)image * tr.n_img;
+    if (image == 1) tr.segs_pending = false;  // imported gradients replace the iteration's: partials left for the optimizer pass are dropped
     for (size_t i = 0; i < tr.layers.size(); ++i) {
         const MlpLayer& l = *tr.layers[i].l;
         if (!W[i] || !b[i]) MTK_FAIL(MTK_ERR_ARG, "mtk_train_import: W[%zu] or b[%zu] is null", i, i);
