@@ -256,7 +256,7 @@ def bench_training(mtk, dev, hidden=1024, batch=2048, steps=200):
         peak = PEAK_TFLOPS["bf16" if prec == "bf16" else "fp32"]
         out[prec] = {"ms_per_step": dt * 1e3, "rows_per_s": batch / dt,
                      "roofline": {"bound": "mfma", "achieved": fl_step / dt / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_step / dt / 1e12 / peak,
-                                  "note": "whole iteration (33 dependent launches at 2,048 rows), not one kernel"}}
+                                  "note": "whole iteration (32 launches at 2,048 rows), not one kernel"}}
         tr.finish()
     return out
 
