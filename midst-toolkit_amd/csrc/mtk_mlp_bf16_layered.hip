@@ -761,8 +761,11 @@ __global__ __launch_bounds__(256) void k_x_to_bf16(uint16_t* dst, int ld, const 
 // v_permlane32_swap pairing, 16-byte stores) — tests/test_gpu_parity.py holds the two against each other with torch.equal.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRingS = 4;
-constexpr int64_t kSmallRowsMax = 4096;  // passes of at most this many (padded) rows (measured, 4 x 1024: 1.7 x at 1 k - 2 k rows, 1.2 x at 4 k,
-                                         // 0.8 x at 8 k: from there the 256 x 256 tiles fill enough of the chip and pull a quarter of the bytes)
+// Pass sizes (padded rows) per tile shape, measured on 4 x 1024 reverse chains (us per step).  64 x 64 against 128 x 128 tiles:
+// 2,048 rows 66.2 / 74.6, 3,072 rows 94.1 / 75.7, 4,096 rows 96.4 / 77.4.  128 x 128 against 256 x 256: 8,192 rows 97.0 / 128.5,
+// 12,288 rows 123.6 / 130.7, 16,384 rows 154.2 / 145.7.  MTK_LAYERED_SMALL_MAX / MTK_LAYERED_MID_MAX move the limits (A/B).
+constexpr int64_t kSmallRowsMax = 2048;   // up to here k_gemm_bf16_s (64 x 64 tiles, two workgroups per CU)
+constexpr int64_t kMidRowsMax = 12288;    // up to here 128 x 128 tiles of the persistent kernel (Geo<4, 1>, two workgroups per CU); beyond, 256 x 256
 constexpr int kStageS = 2 * 64 * 128;  // bytes: record tile (64 rows x 128 B) | weight tile
 extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
 
@@ -914,8 +917,9 @@ int launch(GemmB& g, int device, int64_t Mpad, int Npad, hipStream_t s) {
     if (Mpad % G::BM || Npad % G::BN) MTK_FAIL(MTK_ERR_STATE, "layered bf16 GEMM: %lld x %d is not a multiple of the %d x %d tile", (long long)Mpad, Npad, G::BM, G::BN);
     g.MT = Mpad / G::BM;
     g.nb_n = Npad / G::BN;
-    // one workgroup per CU (160 KB of LDS each); per XCD no more workgroups than its longest tile list
-    int64_t per_xcd = n_cus_layered(device) / 8;
+    // one workgroup per CU (160 KB of LDS each; two where a workgroup's buffers take half of it); per XCD no more workgroups than
+    // its longest tile list
+    int64_t per_xcd = n_cus_layered(device) / 8 * (lds <= 80 * 1024 ? 2 : 1);
     if (per_xcd < 1) per_xcd = 1;
     const int64_t most = ((g.MT + 7) / 8) * g.nb_n;
     if (most < per_xcd) per_xcd = most;
@@ -1101,7 +1105,13 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         }
         int cur = 0;
         // small passes take the 64 x 64-tile kernel (k_gemm_bf16_s: same bits, all CUs busy from 1 k rows on); MTK_LAYERED_BIG: A/B switch
-        const bool small = !SPLIT && Mpad <= kSmallRowsMax && !getenv("MTK_LAYERED_BIG");
+        static const int64_t small_max = getenv("MTK_LAYERED_SMALL_MAX") ? atol(getenv("MTK_LAYERED_SMALL_MAX")) : kSmallRowsMax;  // A/B
+        static const int64_t mid_max = getenv("MTK_LAYERED_MID_MAX") ? atol(getenv("MTK_LAYERED_MID_MAX")) : kMidRowsMax;
+        const bool small = !SPLIT && Mpad <= small_max && !getenv("MTK_LAYERED_BIG");
+        // passes between the two: 128 x 128 tiles of the persistent kernel (80 KB of LDS: two workgroups per CU), four times the
+        // tiles of the 256 x 256 shape for a chip it would leave half empty; MTK_LAYERED_MID=0: A/B switch
+        static const bool no_mid = getenv("MTK_LAYERED_MID") && atoi(getenv("MTK_LAYERED_MID")) == 0;
+        const bool mid = !SPLIT && !small && Mpad <= mid_max && !no_mid && !getenv("MTK_LAYERED_BIG");
         // one timestep for the whole launch (plain bf16): proj is folded into the first block, whose bias is row t of embf_l
         const bool fold = !SPLIT && !t && c->wb16_fold && c->embf_l && t_scalar >= 0 && t_scalar < c->T;
         int ld = kp0;
@@ -1113,7 +1123,10 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
             g.emb = c->d_emb; g.emb_ld = c->emb_ld; g.tvec = t ? t + r0 : nullptr; g.t_scalar = t_scalar; g.T = c->T;
             ld = round_up(c->proj.out_pad, BT);
             g.Y = ws[cur ^ 1]; g.y_rs = (int64_t)F * ld; g.y_lo = ld;
-            if ((rc = small ? launch_small<false, true>(g, c->device, Mpad, ld, s) : launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s))) return rc;
+            if (small) rc = launch_small<false, true>(g, c->device, Mpad, ld, s);
+            else if (mid) rc = launch<false, 4, 1, true, false>(g, c->device, Mpad, ld, s);
+            else rc = launch<false, 2, 4, true, SPLIT>(g, c->device, Mpad, ld, s);
+            if (rc) return rc;
             cur ^= 1;
         }
         for (size_t i = 0; i < c->blocks.size(); ++i) {
@@ -1141,7 +1154,10 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
             h.bias = folded ? c->embf_l + (size_t)t_scalar * c->embf_ld : c->bb16[1 + i]; h.relu = 1;
             ld = round_up(l.out_pad, BT);
             h.Y = ws[cur ^ 1]; h.y_rs = (int64_t)F * ld; h.y_lo = ld;
-            if ((rc = small ? launch_small<false, false>(h, c->device, Mpad, ld, s) : launch<false, 2, 4, false, SPLIT>(h, c->device, Mpad, ld, s))) return rc;
+            if (small) rc = launch_small<false, false>(h, c->device, Mpad, ld, s);
+            else if (mid) rc = launch<false, 4, 1, false, false>(h, c->device, Mpad, ld, s);
+            else rc = launch<false, 2, 4, false, SPLIT>(h, c->device, Mpad, ld, s);
+            if (rc) return rc;
             cur ^= 1;
         }
         GemmB h{};
@@ -1149,7 +1165,8 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         h.X = ws[cur]; h.x_ld = (int64_t)F * ld; h.x_lo = ld;
         h.W = reinterpret_cast<const uint16_t*>(wimg.back()); h.w_ld = (int64_t)F * h.Kpad; h.bias = c->bb16.back();
         h.Y = out + r0 * o_rs; h.y_rs = o_rs; h.y_cs = o_cs;
-        if (small) rc = launch_small<true, false>(h, c->device, Mpad, c->head.out <= 128 ? 128 : round_up(c->head.out_pad, BT), s);
+        // the head of a mid-sized pass stays on the 64 x 64 tiles (N <= 128: the larger tiles leave most CUs without one; measured)
+        if (small || mid) rc = launch_small<true, false>(h, c->device, Mpad, c->head.out <= 128 ? 128 : round_up(c->head.out_pad, BT), s);
         else if (c->head.out <= 128) rc = launch<true, 4, 2, false, SPLIT>(h, c->device, Mpad, 128, s);
         else rc = launch<true, 2, 4, false, SPLIT>(h, c->device, Mpad, round_up(c->head.out_pad, BT), s);
         if (rc) return rc;
