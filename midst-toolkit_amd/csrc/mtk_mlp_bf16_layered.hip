@@ -765,7 +765,10 @@ constexpr int kRingS = 4;
 // 2,048 rows 66.2 / 74.6, 3,072 rows 94.1 / 75.7, 4,096 rows 96.4 / 77.4.  128 x 128 against 256 x 256: 8,192 rows 97.0 / 128.5,
 // 12,288 rows 123.6 / 130.7, 16,384 rows 154.2 / 145.7.  MTK_LAYERED_SMALL_MAX / MTK_LAYERED_MID_MAX move the limits (A/B).
 constexpr int64_t kSmallRowsMax = 2048;   // up to here k_gemm_bf16_s (64 x 64 tiles, two workgroups per CU)
-constexpr int64_t kMidRowsMax = 12288;    // up to here 128 x 128 tiles of the persistent kernel (Geo<4, 1>, two workgroups per CU); beyond, 256 x 256
+// 128 x 128 tiles of the persistent kernel (Geo<4, 1>, two workgroups per CU) while the 256 x 256 tiles of the widest layer number
+// at most kMidTilesMax (three quarters of the CUs: 12,288 rows at 1024 wide), or 256 + at most kMidTailMax (a second round that would
+// be a quarter full: 18,432 rows 204 / 235 us, 20,000 rows 213 / 235, 24,576 rows 244 / 240); otherwise 256 x 256
+constexpr int64_t kMidTilesMax = 192, kMidTailMax = 64;
 constexpr int kStageS = 2 * 64 * 128;  // bytes: record tile (64 rows x 128 B) | weight tile
 extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
 
@@ -1106,12 +1109,16 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
         int cur = 0;
         // small passes take the 64 x 64-tile kernel (k_gemm_bf16_s: same bits, all CUs busy from 1 k rows on); MTK_LAYERED_BIG: A/B switch
         static const int64_t small_max = getenv("MTK_LAYERED_SMALL_MAX") ? atol(getenv("MTK_LAYERED_SMALL_MAX")) : kSmallRowsMax;  // A/B
-        static const int64_t mid_max = getenv("MTK_LAYERED_MID_MAX") ? atol(getenv("MTK_LAYERED_MID_MAX")) : kMidRowsMax;
+        static const int64_t mid_max = getenv("MTK_LAYERED_MID_MAX") ? atol(getenv("MTK_LAYERED_MID_MAX")) : -1;  // A/B: a plain row limit
         const bool small = !SPLIT && Mpad <= small_max && !getenv("MTK_LAYERED_BIG");
         // passes between the two: 128 x 128 tiles of the persistent kernel (80 KB of LDS: two workgroups per CU), four times the
         // tiles of the 256 x 256 shape for a chip it would leave half empty; MTK_LAYERED_MID=0: A/B switch
         static const bool no_mid = getenv("MTK_LAYERED_MID") && atoi(getenv("MTK_LAYERED_MID")) == 0;
-        const bool mid = !SPLIT && !small && Mpad <= mid_max && !no_mid && !getenv("MTK_LAYERED_BIG");
+        // ... chosen by how the 256 x 256 tiles of the widest layer would fill the chip's 256 CUs: at most three quarters of one round
+        // (4 x 1024: up to 12,288 rows), or a second round that is at most a quarter full (16,385 - 20,480 rows)
+        const int64_t tiles_big = (Mpad / BT) * (round_up(maxld, BT) / BT);
+        const bool mid_fill = mid_max >= 0 ? Mpad <= mid_max : (tiles_big <= kMidTilesMax || (tiles_big > 256 && tiles_big <= 256 + kMidTailMax));
+        const bool mid = !SPLIT && !small && mid_fill && !no_mid && !getenv("MTK_LAYERED_BIG");
         // one timestep for the whole launch (plain bf16): proj is folded into the first block, whose bias is row t of embf_l
         const bool fold = !SPLIT && !t && c->wb16_fold && c->embf_l && t_scalar >= 0 && t_scalar < c->T;
         int ld = kp0;
