@@ -769,6 +769,7 @@ constexpr int64_t kSmallRowsMax = 2048;   // up to here k_gemm_bf16_s (64 x 64 t
 // at most kMidTilesMax (three quarters of the CUs: 12,288 rows at 1024 wide), or 256 + at most kMidTailMax (a second round that would
 // be a quarter full: 18,432 rows 204 / 235 us, 20,000 rows 213 / 235, 24,576 rows 244 / 240); otherwise 256 x 256
 constexpr int64_t kMidTilesMax = 192, kMidTailMax = 64;
+constexpr int64_t kFirstSmallRowsMax = 8192;  // the state-input first block on 64 x 64 tiles (k_first_state_s) up to here
 constexpr int kStageS = 2 * 64 * 128;  // bytes: record tile (64 rows x 128 B) | weight tile
 extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
 
@@ -881,6 +882,122 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_s(GemmB g) {
             *reinterpret_cast<uint4*>(yb + 8 * (2 * p2 + (hh ? 0 : 1))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
     }
+}
+
+// The state-input first block (k_first_state) on 64 x 64 tiles, for the passes that take the smaller tiles above: at 1,024 rows the
+// 256 x 256 kernel runs on 16 workgroups and its one tile per workgroup is a chain of round trips (weights, state, build, MFMAs,
+// stores: 15 us whatever the rows).  Here a workgroup builds the operand rows of its 64 records (thread = record x quarter of the
+// 16-byte pieces), takes its 64 x K weight tile by LDS-DMA and multiplies once.  Same operand bits (fp64 -> fp32 -> bf16 kept as two
+// roundings, log(1e-30) as bf16, zeros on the hot columns), same bias start, same k order: the same output bits.
+__global__ __launch_bounds__(256) void k_first_state_s(FirstArgs g) {
+    constexpr int kOp = 64 * 128;  // bytes of one k-block of the record or of the weight tile
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    unsigned char* lds = gs_smem;              // [nkb][64][128 B] record image
+    unsigned char* ldsW = gs_smem + 2 * kOp;   // [nkb][64][128 B] weight image
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    f32x16 acc;
+    {
+        const float* bp = g.bias + n0 + wc * 32 + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + 8 * q);
+            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+        }
+    }
+    // weight tile: wave wv moves rows [16 wv, 16 wv + 16), two 8-row pieces per k-block (swizzle as in k_gemm_bf16_s)
+    {
+        const int lr = lane >> 3;
+        for (int kb = 0; kb < g.nkb; ++kb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lc = (lane & 7) ^ ((4 * j + (lr >> 1)) & 7);
+                const unsigned voff = (unsigned)(lr * g.w_ld * 2 + lc * 16);
+                const unsigned char* gp = reinterpret_cast<const unsigned char*>(g.W + ((int64_t)n0 + 16 * wv + 8 * j) * g.w_ld + kb * BK);
+                const unsigned m0v = (unsigned)(2 * kOp + kb * kOp + wv * 2048 + j * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gp), "s"(m0v) : "memory");
+            }
+    }
+    // record image: thread (r, quarter) owns the pieces p = quarter, quarter + 4, ... of record r's row
+    {
+        const __bf16 cold_b = (__bf16)MTK_LOG_TINY;
+        const uint16_t cold = *reinterpret_cast<const uint16_t*>(&cold_b);
+        const int r = tid & 63, quarter = wv;
+        const int64_t row = m0 + r;
+        const bool live = row < g.M;
+        const int64_t rowc = live ? row : g.M - 1;
+        const int kz = g.Nn > 0 ? g.Nn - 1 : 0, kc = g.C > 0 ? g.C - 1 : 0;
+        const int np = g.nkb * 8;
+        unsigned char* rowp = lds + r * 128;
+        const int key = (r >> 1) & 7;
+        int idx[kStateMaxC];
+#pragma unroll
+        for (int k = 0; k < kStateMaxC; ++k) idx[k] = g.z_idx[(int64_t)(k < kc ? k : kc) * g.ld + rowc];
+        for (int p = quarter; p < np; p += 4) {
+            uint16_t v[8];
+            if (p * 8 < g.Nn) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = p * 8 + i;
+                    float zf = (float)g.z[(int64_t)(k < kz ? k : kz) * g.ld + rowc];
+                    asm volatile("" : "+v"(zf));  // two roundings (fp64 -> fp32 -> bf16), not one: see k_first_state
+                    const __bf16 b = (__bf16)zf;
+                    const uint16_t e = (k < g.Nn) ? *reinterpret_cast<const uint16_t*>(&b) : ((k < g.D) ? cold : (uint16_t)0);
+                    v[i] = live ? e : (uint16_t)0;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (live && p * 8 + i < g.D) ? cold : (uint16_t)0;
+            }
+            *reinterpret_cast<uint4*>(rowp + (p >> 3) * kOp + (((p & 7) ^ key) * 16)) =
+                make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16));
+        }
+        asm volatile("" ::: "memory");  // the fills before the two-byte pokes of the same thread (LDS operations of a wave execute in order)
+#pragma unroll
+        for (int k = 0; k < kStateMaxC; ++k) {
+            if (k < g.C && live && idx[k] >= 0) {
+                const int col = g.Nn + g.off[k] + idx[k];
+                const int p = col >> 3;
+                if ((p & 3) == quarter && p < np)
+                    *reinterpret_cast<uint16_t*>(rowp + (p >> 3) * kOp + (((p & 7) ^ key) * 16) + (col & 7) * 2) = 0;  // log(1) on the hot column
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ns = g.nkb * 4;
+    for (int sidx = 0; sidx < ns; ++sidx) {
+        const int kb = sidx >> 2, kp = (sidx & 3) * 2 + hh;
+        const int rx = wr * 32 + li, rw = wc * 32 + li;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + kb * kOp + rx * 128 + ((kp ^ ((rx >> 1) & 7)) * 16));
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ldsW + kb * kOp + rw * 128 + ((kp ^ ((rw >> 1) & 7)) * 16));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+    }
+    // epilogue of k_first_state for one 32 x 32 sub-tile
+    const int64_t row = m0 + wr * 32 + li;
+    unsigned pk[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const __bf16 e[4] = {(__bf16)fmaxf(acc[4 * q], 0.0f), (__bf16)fmaxf(acc[4 * q + 1], 0.0f), (__bf16)fmaxf(acc[4 * q + 2], 0.0f), (__bf16)fmaxf(acc[4 * q + 3], 0.0f)};
+        pk[q][0] = reinterpret_cast<const unsigned*>(e)[0];
+        pk[q][1] = reinterpret_cast<const unsigned*>(e)[1];
+    }
+    uint16_t* yb = g.Y + row * g.y_rs + n0 + wc * 32;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][0], pk[2 * p2][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2 + 1][1], pk[2 * p2][1], false, false);
+        *reinterpret_cast<uint4*>(yb + 8 * (2 * p2 + (hh ? 0 : 1))) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+
+int launch_first_state_small(FirstArgs& g, int64_t Mpad, int Npad, hipStream_t s) {
+    if (Mpad % 64 || Npad % 64 || g.nkb < 1 || g.nkb > 2 || Mpad / 64 > 65535 * 32) MTK_FAIL(MTK_ERR_STATE, "state-input block (small tiles): %lld x %d, %d k-blocks", (long long)Mpad, Npad, g.nkb);
+    hipLaunchKernelGGL(k_first_state_s, dim3((unsigned)(Mpad / 64), (unsigned)(Npad / 64)), dim3(256), 4 * 64 * 128, s, g);
+    MTK_HIP(hipGetLastError());
+    return MTK_OK;
 }
 
 template <bool OF32, bool EMB>
@@ -1150,7 +1267,10 @@ int forward_layered(mtk_ctx* c, int64_t B, const float* x, int64_t x_rs, int64_t
                 f.bias = c->embf_l + (size_t)t_scalar * c->embf_ld;
                 ld = round_up(l.out_pad, BT);
                 f.Y = ws[cur ^ 1]; f.y_rs = ld;
-                if ((rc = launch_first_state(c, f, Mpad, ld, s))) return rc;
+                static const bool first_big = getenv("MTK_FIRST_STATE_BIG") != nullptr;  // A/B: the 256 x 256 kernel at every pass size
+                // measured, 4 x 1024 chain, us per step with the 64 x 64 / the 256 x 256 first block: 1,024 rows 54.7 / 63.4, 4,096 rows
+                // 71.7 / 77.4, 8,192 rows 95.6 / 95.9, 12,288 rows 127.7 / 121.1
+                if ((rc = (Mpad <= kFirstSmallRowsMax && !first_big) ? launch_first_state_small(f, Mpad, ld, s) : launch_first_state(c, f, Mpad, ld, s))) return rc;
                 cur ^= 1;
                 continue;
             }
