@@ -1010,7 +1010,7 @@ def test_caller_sized_reverse_step_equals_the_general_kernel(monkeypatch, K, Nn)
                                      # 2,048 < rows <= 12,288: the persistent kernel on 128 x 128 tiles (the 4,096- and 3,900-row cases above too)
                                      ((120, [1024] * 4), 8192), ((142, [512, 1024, 1024, 1024, 1024, 512]), 12001), ((40, [128, 256]), 5000),
                                      # 284 tiles of 256 x 256: a second round that would be a ninth full -> 128 x 128 tiles as well
-                                     ((120, [1024] * 4), 18000)])
+                                     ((120, [1024] * 4), 18000), ((142, [512, 1024, 1024, 1024, 1024, 512]), 20000)])
 def test_small_pass_layered_kernel_equals_the_big_tile(monkeypatch, shape, B):
     """Round 3: passes of at most 2,048 rows run the layered denoiser on 64 x 64 tiles (k_gemm_bf16_s: every CU busy from 1 k rows
     on - the batch sizes the reference's callers sample, SYNTH:79), passes of up to 12,288 rows on 128 x 128 tiles of the persistent
