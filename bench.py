@@ -19,7 +19,8 @@ other modes, each with its own roofline fraction, measured after the timed regio
   mixed_loss_shapeM                 evals/s of q_sample -> denoiser -> loss_rows at shape M with the three kernels' rates
   parity_fp32 / parity_bf16x3       the headline workload in the two modes that carry the 1e-4 parity bar
   training_2048x4x1024              one ClavaDDPMTrainer iteration at BASELINE configs[4]'s per-rank shape, bf16 and fp32 GEMMs
-  sampling_caller_sized             microseconds per reverse step at 1,024 / 8,192 rows (what the reference's callers sample per call)
+  sampling_caller_sized             microseconds per reverse step at 1,024 / 8,192 rows (what the reference's callers sample per call):
+                                    4 x 512, 4 x 1024 and ClavaDDPM's default 512-1024-1024-1024-1024-512 denoiser
 """
 import argparse
 import json
@@ -174,9 +175,10 @@ def bench_sampling_small(mtk, dev):
     K, Nn, T = np.array([10] * 10), 20, 1000
     D = Nn + int(K.sum())
     out = {"T": T, "rng": "philox (in-kernel)", "math": "fast", "unit": "us per reverse step"}
-    for hidden in (512, 1024):
+    # 4 x 512 (BASELINE configs[1]'s denoiser), 4 x 1024 (configs[3] / [4]) and ClavaDDPM's default six-layer denoiser
+    for name, layers in (("4x512", [512] * 4), ("4x1024", [1024] * 4), ("clavaddpm_default_512_1024x4_512", [512, 1024, 1024, 1024, 1024, 512])):
         torch.manual_seed(0)
-        net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([hidden] * 4, 0.0))
+        net = mtk.MLPDiffusion(D, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters(list(layers), 0.0))
         net.precision = "bf16"
         d = mtk.GaussianMultinomialDiffusion(K, Nn, net, num_timesteps=T, device=dev).to(dev)
         d.precision, d.rng, d.results_on_device = "bf16", "philox", True
@@ -188,7 +190,7 @@ def bench_sampling_small(mtk, dev):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             assert bool(torch.isfinite(x).all())
-            out[f"4x{hidden}_{rows}_rows"] = {"us_per_step": dt / T * 1e6, "sampled_rows_per_s": rows / dt}
+            out[f"{name}_{rows}_rows"] = {"us_per_step": dt / T * 1e6, "sampled_rows_per_s": rows / dt}
     return out
 
 

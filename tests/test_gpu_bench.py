@@ -42,7 +42,8 @@ def test_bench_line_single_gpu():
     trn = ex["training_2048x4x1024"]  # one trainer iteration at configs[4]'s per-rank shape, both GEMM precisions
     assert 0 < trn["bf16"]["ms_per_step"] < trn["fp32"]["ms_per_step"] and trn["rows"] == 2048
     small = ex["sampling_caller_sized"]  # microseconds per reverse step at the batch sizes the reference's callers sample
-    assert all(small[k]["us_per_step"] > 0 for k in ("4x512_1024_rows", "4x512_8192_rows", "4x1024_1024_rows", "4x1024_8192_rows"))
+    assert all(small[k]["us_per_step"] > 0 for k in ("4x512_1024_rows", "4x512_8192_rows", "4x1024_1024_rows", "4x1024_8192_rows",
+                                                    "clavaddpm_default_512_1024x4_512_1024_rows", "clavaddpm_default_512_1024x4_512_8192_rows"))
 
 
 def test_bench_two_rank_rehearsal():
