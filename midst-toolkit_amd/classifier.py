@@ -175,7 +175,12 @@ class Classifier(nn.Module):
                                       "Dropout), which is how the synthesizer calls it (TRAIN:447): call classifier.eval() first")
         dev = x.device
         h = self._engine(dev)
-        xf = x.detach().float().contiguous()
+        xd = x.detach()
+        if xd.dtype == torch.float32 and xd.is_contiguous():
+            xf = xd
+        else:  # one kernel also for a transposed fp64 view (the chain's state): conversion and layout in the same copy
+            xf = torch.empty(tuple(xd.shape), dtype=torch.float32, device=dev)
+            xf.copy_(xd)
         B = xf.shape[0]
         t = timesteps.to(dev, torch.int64).contiguous()
         yy = y.to(dev, torch.int64).view(-1).contiguous() if y is not None else None

@@ -525,7 +525,7 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                 eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed, row0, grad=grad)
                 continue
             if conditioning_function is not None and Nn:
-                feats = z[:Nn].t().contiguous()
+                feats = z[:Nn].t()  # [B, Nn] view of the column-major state: the classifier's input conversion makes the one copy
                 if i == 0:
                     feats = feats.float()
                 tvec = torch.full((B,), t, device=dev, dtype=torch.long)
