@@ -268,4 +268,5 @@ def get_conditioning_function(classifier: Classifier, classifier_scale: float):
         x = features[:, 1:] if kwargs.get("remove_first_col", False) else features
         return classifier.guidance_gradient(x, timestep, kwargs["y"], classifier_scale)
 
+    conditioning_function._mtk_stream_safe = True  # no random draws, all work on the current stream: the chain may run it on a side stream
     return conditioning_function

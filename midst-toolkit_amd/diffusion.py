@@ -502,7 +502,28 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
         x_in = None if from_state else torch.empty((D, B), dtype=torch.float32, device=dev)
         out = torch.empty((D, B), dtype=torch.float32, device=dev)
         eng.sample_init(B, z0, u0, z, z_idx, x_in, (1, B), seed, row0)
+        # Classifier guidance (GMD:1319-1368) needs the state and the timestep, not the denoiser's output: its forward / input
+        # gradient runs on a side stream beside the denoiser and joins before the posterior step (a guided step at caller-sized
+        # batches is two chains of small dependent launches; `guidance_stream = False` keeps everything on one stream)
+        side = None
+        # (only for this package's own conditioning function, classifier.get_conditioning_function: it draws no random numbers and
+        # issues all its work on the current stream; any other callable keeps its place after the step's draws on the one stream)
+        if (conditioning_function is not None and Nn and not ddim and getattr(self, "guidance_stream", True)
+                and getattr(conditioning_function, "_mtk_stream_safe", False)):
+            side = self.__dict__.get("_guidance_side")
+            if side is None or side.device != dev:
+                side = self.__dict__["_guidance_side"] = torch.cuda.Stream(device=dev)
         for i, t in enumerate(reversed(range(T))):
+            grad_side = None
+            if side is not None:
+                cur = torch.cuda.current_stream(dev)
+                side.wait_stream(cur)  # the previous step's state
+                with torch.cuda.stream(side):
+                    feats = z[:Nn].t()
+                    if i == 0:
+                        feats = feats.float()
+                    tvec = torch.full((B,), t, device=dev, dtype=torch.long)
+                    grad_side = conditioning_function(feats, tvec, **model_kwargs).detach().to(device=dev, dtype=torch.float32).contiguous()
             if from_state:  # GMD:1406's cat[z_norm, log_z].float() is formed inside the denoiser's first block
                 eng.mlp_forward_state(z, z_idx, t, out, B, self.precision, out_strides=(1, B))
             else:
@@ -524,7 +545,10 @@ class GaussianMultinomialDiffusion(torch.nn.Module):
                     grad = grad.detach().to(device=dev, dtype=torch.float32).contiguous()
                 eng.ddim_step(B, t, out, (1, B), z, z_idx, u, x_in, (1, B), seed, row0, grad=grad)
                 continue
-            if conditioning_function is not None and Nn:
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                grad = grad_side
+            elif conditioning_function is not None and Nn:
                 feats = z[:Nn].t()  # [B, Nn] view of the column-major state: the classifier's input conversion makes the one copy
                 if i == 0:
                     feats = feats.float()

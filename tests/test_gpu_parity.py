@@ -1812,6 +1812,11 @@ def test_classifier_guidance_on_hip():
     close(got, want, rtol=RTOL, atol=max(1e-5, 3 * own))
     plain, _ = d.sample(targets.shape[0], torch.ones(3), _injected=dict(inj, y=torch.zeros(targets.shape[0], dtype=torch.long)))
     assert float((plain - want).abs().max()) > 1e-2  # the guidance moved the chain
+    # the chain runs this package's conditioning function on a side stream beside the denoiser (it needs the state, not the
+    # denoiser's output): the same samples as with everything on one stream
+    d.guidance_stream = False
+    one_stream, _ = d.conditional_sample(targets, model_kwargs={"y": targets.to(dev())}, conditioning_function=cond, _injected=inj)
+    assert torch.equal(one_stream, got)
 
 
 @pytest.mark.parametrize("tag,precision", [("M_mixed", "bf16"), ("B_ragged", "bf16x3"), ("B_ragged", "fp32")])
