@@ -19,6 +19,7 @@ other modes, each with its own roofline fraction, measured after the timed regio
   mixed_loss_shapeM                 evals/s of q_sample -> denoiser -> loss_rows at shape M with the three kernels' rates
   parity_fp32 / parity_bf16x3       the headline workload in the two modes that carry the 1e-4 parity bar
   training_2048x4x1024              one ClavaDDPMTrainer iteration at BASELINE configs[4]'s per-rank shape, bf16 and fp32 GEMMs
+  sampling_guided_caller_sized      microseconds per classifier-guided reverse step at 1,024 / 8,192 rows (ClavaDDPM default denoiser and classifier)
   sampling_caller_sized             microseconds per reverse step at 1,024 / 8,192 rows (what the reference's callers sample per call):
                                     4 x 512, 4 x 1024 and ClavaDDPM's default 512-1024-1024-1024-1024-512 denoiser
 """
@@ -191,6 +192,31 @@ def bench_sampling_small(mtk, dev):
             dt = time.perf_counter() - t0
             assert bool(torch.isfinite(x).all())
             out[f"{name}_{rows}_rows"] = {"us_per_step": dt / T * 1e6, "sampled_rows_per_s": rows / dt}
+    return out
+
+
+def bench_sampling_guided(mtk, dev):
+    """Classifier-guided reverse chain (GMD:1319 conditional_sample, what ClavaDDPM runs for child tables) at caller-sized batches:
+    microseconds per step with ClavaDDPM's default denoiser (bf16) and default guidance classifier (fp32: parity-grade gradient)."""
+    Nn, T, n_cls = 20, 200, 12
+    torch.manual_seed(0)
+    net = mtk.MLPDiffusion(Nn, 0, mtk.IsTargetConditioned.NONE, mtk.DiffusionParameters([512, 1024, 1024, 1024, 1024, 512], 0.0))
+    net.precision = "bf16"
+    d = mtk.GaussianMultinomialDiffusion(np.asarray([0]), Nn, net, num_timesteps=T, device=dev).to(dev)
+    d.precision, d.rng, d.results_on_device = "bf16", "philox", True
+    clf = mtk.Classifier(Nn, n_cls, 128, [128, 256, 512, 1024, 512, 256, 128], dropout_prob=0.1).to(dev).eval()
+    cond = mtk.get_conditioning_function(clf, 1.0)
+    out = {"T": T, "denoiser": "512-1024x4-512 bf16", "classifier": "128-256-512-1024-512-256-128 fp32", "numeric_features": Nn, "unit": "us per guided reverse step"}
+    for rows in (1024, 8192):
+        y = torch.randint(0, n_cls, (rows,), device=dev)
+        d.conditional_sample(y.cpu(), model_kwargs={"y": y}, conditioning_function=cond)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, _ = d.conditional_sample(y.cpu(), model_kwargs={"y": y}, conditioning_function=cond)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(x).all())
+        out[f"{rows}_rows"] = {"us_per_step": dt / T * 1e6, "sampled_rows_per_s_at_T1000": rows / (dt / T * 1000)}
     return out
 
 
@@ -469,6 +495,7 @@ def main():
         extras["mixed_loss_shapeM"] = bench_mixed_loss(mtk, dev, 1 << 20)
         extras["training_2048x4x1024"] = bench_training(mtk, dev)
         extras["sampling_caller_sized"] = bench_sampling_small(mtk, dev)
+        extras["sampling_guided_caller_sized"] = bench_sampling_guided(mtk, dev)
         for prec, nt_p in (("fp32", 10), ("bf16x3", 20)):  # the modes that carry the <= 1e-4 parity bar, same records
             if prec == a.precision:
                 continue

@@ -41,6 +41,7 @@ def test_bench_line_single_gpu():
     assert ex["parity_fp32"]["evals_per_s"] > 0 and ex["parity_bf16x3"]["evals_per_s"] > ex["parity_fp32"]["evals_per_s"]
     trn = ex["training_2048x4x1024"]  # one trainer iteration at configs[4]'s per-rank shape, both GEMM precisions
     assert 0 < trn["bf16"]["ms_per_step"] < trn["fp32"]["ms_per_step"] and trn["rows"] == 2048
+    assert all(ex["sampling_guided_caller_sized"][k]["us_per_step"] > 0 for k in ("1024_rows", "8192_rows"))
     small = ex["sampling_caller_sized"]  # microseconds per reverse step at the batch sizes the reference's callers sample
     assert all(small[k]["us_per_step"] > 0 for k in ("4x512_1024_rows", "4x512_8192_rows", "4x1024_1024_rows", "4x1024_8192_rows",
                                                     "clavaddpm_default_512_1024x4_512_1024_rows", "clavaddpm_default_512_1024x4_512_8192_rows"))
