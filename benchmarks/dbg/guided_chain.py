@@ -13,6 +13,7 @@ net.precision = "bf16"
 d = mtk.GaussianMultinomialDiffusion(np.asarray([0]), Nn, net, num_timesteps=T, device=dev).to(dev)
 d.precision, d.rng, d.results_on_device = "bf16", "philox", True
 clf = mtk.Classifier(Nn, n_cls, 128, [128, 256, 512, 1024, 512, 256, 128], dropout_prob=0.1).to(dev).eval()
+clf.precision = os.environ.get("CLF_PRECISION", "fp32")
 cond = mtk.get_conditioning_function(clf, 1.0)
 for B in ([int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1024, 8192, 20000)):
     y = torch.randint(0, n_cls, (B,), device=dev)
@@ -25,4 +26,4 @@ for B in ([int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (10
         run(); torch.cuda.synchronize()
         t0 = time.perf_counter(); run(); torch.cuda.synchronize()
         res["guided" if guided else "plain"] = (time.perf_counter() - t0) / T * 1e6
-    print(json.dumps({"rows": B, "T": T, "us_per_step_plain": res["plain"], "us_per_step_guided": res["guided"]}), flush=True)
+    print(json.dumps({"classifier": clf.precision, "rows": B, "T": T, "us_per_step_plain": res["plain"], "us_per_step_guided": res["guided"]}), flush=True)

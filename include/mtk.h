@@ -417,6 +417,11 @@ typedef struct mtk_clf mtk_clf;
 int mtk_clf_create(int device, int T, int D_in, int dim_t, int n_lin, const int32_t* widths_host, const float* slopes_host,
                    const float* const* W, const float* const* b, const float* freqs_host, mtk_stream stream, mtk_clf** out);
 void mtk_clf_destroy(mtk_clf* clf);
+/* MTK_PREC_FP32 (default: fp32 MFMA, the reference's arithmetic for SYNTH:429-451) or MTK_PREC_BF16X3: every GEMM of the guidance as a
+ * split-bf16 product (operands carried as hi + lo bf16 numbers, three bf16 MFMAs per product, fp32 accumulation and storage) -
+ * logits and input gradients within ~1e-3 of their scale at several times the fp32 rate.  Plain bf16 operands are refused: the
+ * input gradient through the classifier's layers is a sum with heavy cancellation.  No counterpart in the reference. */
+int mtk_clf_set_precision(mtk_clf* clf, int precision);
 /* x: [B, x_ld] row-major fp32 (x_ld >= D_in); t: [B] int64; y: [B] int64 class indices (needed for grad).  logits: [B, n_out]
  * row-major or NULL; grad: [B, D_in] row-major or NULL.  Rows whose timestep lies outside [0, T) come back NaN. */
 int mtk_clf_guidance(mtk_clf* clf, int64_t B, const float* x, int64_t x_ld, const int64_t* t, const int64_t* y, double scale,

@@ -79,6 +79,7 @@ _SIGS = {
     "mtk_train_apply": (C.c_int, [_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _p]),
     "mtk_clf_create": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, C.POINTER(_p)]),
     "mtk_clf_destroy": (None, [_p]),
+    "mtk_clf_set_precision": (C.c_int, [_p, _i32]),
     "mtk_clf_guidance": (C.c_int, [_p, _i64, _p, _i64, _p, _p, C.c_double, _p, _p, _p]),
     "mtk_edm_create": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, C.POINTER(_p)]),
     "mtk_edm_destroy": (None, [_p]),

@@ -43,6 +43,9 @@ class Classifier(nn.Module):
         self.model = nn.Sequential(*layers)
         self._handle = None
         self._handle_key = None
+        # "fp32" (the reference's arithmetic) or "bf16x3": the guidance GEMMs as split-bf16 products (mtk_clf_set_precision; ~1e-3 of
+        # the gradient's scale at several times the fp32 rate) - for long guided chains; not in the reference
+        self.precision = "fp32"
         self._train_handle = None   # mtk_clft: training-mode forward / backward
         self._train_key = None
         self.dropout_seed = 0       # base key of the Philox dropout masks (a fresh mask per training forward)
@@ -175,6 +178,9 @@ class Classifier(nn.Module):
                                       "Dropout), which is how the synthesizer calls it (TRAIN:447): call classifier.eval() first")
         dev = x.device
         h = self._engine(dev)
+        if self.precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"Classifier.precision: {self.precision!r} (fp32 or bf16x3)")
+        check(_lib.lib().mtk_clf_set_precision(h, _lib.PREC_BF16X3 if self.precision == "bf16x3" else _lib.PREC_FP32))
         xd = x.detach()
         if xd.dtype == torch.float32 and xd.is_contiguous():
             xf = xd

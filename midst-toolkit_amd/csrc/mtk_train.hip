@@ -63,6 +63,7 @@ struct G2 {
     // mask (kept and positive <=> stored value > 0), so the backward only needs the scale: mask_scale (0 reads as 1).
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed, drop_row0; int drop_layer;
     float mask_scale;
+    int x3;                        // split-bf16 product of fp32 operands (k_gemm2x): 64 x 64 tiles, fp32 result; no row sums, no bf16 operands
     int dma;                       // the caller vouches for k_gemm2c's conditions (see there): 1 = B has rows up to the next
                                    // multiple of 64 past N, 2 = of 128
 };
@@ -319,6 +320,14 @@ __device__ __forceinline__ unsigned g2_pack2(float a, float b) {
     return *reinterpret_cast<const unsigned*>(e);
 }
 
+// LO: the part the bf16 rounding left behind, itself rounded to bf16 (split-bf16: v ~ hi + lo to 2^-17 relative)
+template <bool LO>
+__device__ __forceinline__ unsigned g2_pack2x(float a, float b) {
+    if constexpr (!LO) return g2_pack2(a, b);
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+    return g2_pack2(a - (float)ha, b - (float)hb);
+}
+
 // SRC16 = false: fp32 source, rounded on the way into LDS.  SRC16 = true: bf16 source, copied.
 template <bool TR, int T, bool SRC16>
 struct TileMoverB;
@@ -357,12 +366,12 @@ struct TileMoverB<TR, T, false> {
             reg<Q>() = ok ? v : v4f{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
-    template <int Q>
+    template <int Q, bool LO = false>
     __device__ __forceinline__ void store_q(uint16_t* lds, int tid) {
         if (!TR) {
             const int idx = tid + 256 * Q, rr = idx >> 4, c = (idx & 15) * 4;
             const v4f v = reg<Q>();
-            *reinterpret_cast<uint2*>(&lds[rr * PITCH2 + c]) = make_uint2(g2_pack2(v[0], v[1]), g2_pack2(v[2], v[3]));
+            *reinterpret_cast<uint2*>(&lds[rr * PITCH2 + c]) = make_uint2(g2_pack2x<LO>(v[0], v[1]), g2_pack2x<LO>(v[2], v[3]));
         } else if constexpr ((Q & 1) == 0) {
             const int idx = tid + 256 * (Q >> 1), kp = idx / (T / 4), rq = (idx % (T / 4)) * 4;
             const v4f lo = reg<Q>(), hi = reg<Q + 1>();
@@ -373,7 +382,7 @@ struct TileMoverB<TR, T, false> {
             for (int j = 0; j < 4; ++j) {
                 const int jj = (j + rot) & 3;
                 const float a = mtk_pick4f(lo[0], lo[1], lo[2], lo[3], jj), b = mtk_pick4f(hi[0], hi[1], hi[2], hi[3], jj);
-                *reinterpret_cast<unsigned*>(&lds[(rq + jj) * PITCH2 + 2 * kp]) = g2_pack2(a, b);
+                *reinterpret_cast<unsigned*>(&lds[(rq + jj) * PITCH2 + 2 * kp]) = g2_pack2x<LO>(a, b);
             }
         }
     }
@@ -386,6 +395,11 @@ struct TileMoverB<TR, T, false> {
     __device__ __forceinline__ void store(uint16_t* lds, int tid) {
         store_q<Q>(lds, tid);
         if constexpr (Q + 1 < NLD) store<Q + 1>(lds, tid);
+    }
+    template <int Q = 0>
+    __device__ __forceinline__ void store_lo(uint16_t* lds, int tid) {  // the low parts of the same registers, same layout
+        store_q<Q, true>(lds, tid);
+        if constexpr (Q + 1 < NLD) store_lo<Q + 1>(lds, tid);
     }
 };
 
@@ -676,6 +690,55 @@ __global__ __launch_bounds__(256) void k_gemm2b(G2 g) {
     gemm2b_finish<WT, WT, DROP>(g, acc, rs, sum_rows, smem, m0, n0, lane, wid);
 }
 
+// Split-bf16 product of fp32 operands (the guidance classifier's MTK_PREC_BF16X3 mode): k_gemm2b's 64 x 64 tile with every fp32 value
+// carried into LDS as hi = bf16(v) and lo = bf16(v - hi), and a.b ~ ah.bh + al.bh + ah.bl - three bf16 MFMAs per product into the
+// same fp32 accumulators (the dropped al.bl term is ~2^-16 of the product), against sixteen fp32 MFMAs at a sixteenth of the rate.
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void k_gemm2x(G2 g) {
+    constexpr int T = 64;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[4 * T * PITCH2];
+    uint16_t* const Ah = smem;
+    uint16_t* const Bh = smem + T * PITCH2;
+    uint16_t* const Al = smem + 2 * T * PITCH2;
+    uint16_t* const Bl = smem + 3 * T * PITCH2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * T;
+    const int n0 = blockIdx.y * T;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    float rs[1] = {0.0f};
+    TileMoverB<AT, T, false> ma;
+    TileMoverB<BT, T, false> mb;
+    ma.load(g.A, g.lda, m0, kbeg, kend, tid);
+    mb.load(g.B, g.ldb, n0, kbeg, kend, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += KB2) {
+        ma.store(Ah, tid);
+        ma.store_lo(Al, tid);
+        mb.store(Bh, tid);
+        mb.store_lo(Bl, tid);
+        __syncthreads();
+        if (k0 + KB2 < kend) {
+            ma.load(g.A, g.lda, m0, k0 + KB2, kend, tid);
+            mb.load(g.B, g.ldb, n0, k0 + KB2, kend, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < KB2 / 16; ++s) {
+            const int oa = (wr * 32 + li) * PITCH2 + 16 * s + 8 * hh, ob = (wc * 32 + li) * PITCH2 + 16 * s + 8 * hh;
+            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(&Ah[oa]), al = *reinterpret_cast<const bf16x8_t*>(&Al[oa]);
+            const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(&Bh[ob]), bl = *reinterpret_cast<const bf16x8_t*>(&Bl[ob]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[0][0], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm2b_finish<1, 1, false>(g, acc, rs, false, smem, m0, n0, lane, wid);
+}
+
 // The GEMM most of a bf16 iteration runs in: both operands bf16, both read along their rows (the transposed copies exist for
 // this), 64 x 64 tiles.  k_gemm2b holds ONE k-step in registers on its way to LDS, and with two workgroups on a CU a k-step then
 // costs a global round trip (14.7 us for 2,048 x 1,024 x 1,024: 35 GB/s per CU from an L2 that holds both operands).  Here the
@@ -821,6 +884,12 @@ int launch(const G2& g, hipStream_t s) {
     const int splits = (g.K + g.kchunk - 1) / g.kchunk;
     const int64_t wg128 = (int64_t)(g.M / TM) * ((g.N + TN - 1) / TN) * splits;
     const dim3 g128((unsigned)(g.M / 128), (unsigned)((g.N + 127) / 128), (unsigned)splits), g64((unsigned)(g.M / 64), (unsigned)((g.N + 63) / 64), (unsigned)splits);
+    if (g.x3) {
+        if (g.a16 || g.b16 || g.c16 || g.rowsum || g.rowsum_slab || g.drop_thresh != 0) MTK_FAIL(MTK_ERR_STATE, "split-bf16 GEMM: fp32 operands and result only");
+        hipLaunchKernelGGL((k_gemm2x<AT, BT>), g64, dim3(256), 0, s, g);
+        MTK_HIP(hipGetLastError());
+        return MTK_OK;
+    }
     static const bool old_bf = getenv("MTK_TRAIN_BF16_OLD") != nullptr;  // A/B: the round-2 bf16 instantiation (fp32 tiles in LDS)
     static const bool no_dma = getenv("MTK_TRAIN_NO_DMA") != nullptr;    // A/B: k_gemm2b where k_gemm2c would run
     if (g.bf16 && !old_bf && !no_dma && g.dma && !AT && !BT && g.a16 && g.b16 && g.K % 64 == 0 && (g.kchunk % 64 == 0 || g.kchunk == g.K)) {
@@ -2038,6 +2107,7 @@ struct mtk_clf {
     float* xin = nullptr;           // [cap][proj.in_pad]
     std::vector<float*> act;        // act[0] = h0 [cap][proj.out_pad]; act[i + 1] = output of Linear i [cap][lin[i].out_pad]
     float* d[2] = {nullptr, nullptr};  // gradient ping-pong [cap][widest padded layer]
+    int x3 = 0;                     // mtk_clf_set_precision(MTK_PREC_BF16X3): the GEMMs as split-bf16 products (k_gemm2x)
 };
 
 namespace {
@@ -2208,6 +2278,14 @@ extern "C" int mtk_clf_create(int device, int T, int D_in, int dim_t, int n_lin,
     return MTK_OK;
 }
 
+extern "C" int mtk_clf_set_precision(mtk_clf* c, int precision) {
+    if (!c) MTK_FAIL(MTK_ERR_ARG, "mtk_clf_set_precision: null classifier");
+    if (precision != MTK_PREC_FP32 && precision != MTK_PREC_BF16X3)
+        MTK_FAIL(MTK_ERR_ARG, "mtk_clf_set_precision: precision %d (MTK_PREC_FP32 or MTK_PREC_BF16X3; plain bf16 operands do not carry the input gradient)", precision);
+    c->x3 = precision == MTK_PREC_BF16X3 ? 1 : 0;
+    return MTK_OK;
+}
+
 // logits (optional, [B, n_out] row-major) and / or grad (optional, [B, D_in] row-major fp32):
 // grad = scale * d log_softmax(logits)[y] / d x.  x: [B, x_ld] row-major fp32; t: [B] int64 (clamped into [0, T) for
 // addressing; rows with a timestep outside it come back NaN); y: [B] int64 class indices (required with grad).
@@ -2227,6 +2305,7 @@ extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x
     hipLaunchKernelGGL(k_clf_pad_rows, dim3(1024), dim3(256), 0, s, c->xin, c->proj.in_pad, x, x_ld, B, Mpad, c->D_in);
     {   // h0 = proj(x) + emb[t]   (MODEL:118-119)
         G2 g{};
+        g.x3 = c->x3;
         g.M = (int)Mpad; g.N = c->proj.out_pad; g.K = c->proj.in_pad; g.kchunk = g.K;
         g.A = c->xin; g.lda = c->proj.in_pad; g.B = c->proj.w32; g.ldb = c->proj.in_pad;
         g.C = c->act[0]; g.c_rs = c->proj.out_pad; g.c_cs = 1; g.bias = c->proj.b32;
@@ -2236,6 +2315,7 @@ extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x
     for (int i = 0; i < c->n_lin; ++i) {   // MODEL:95-117 in eval mode
         MlpLayer& l = c->lin[i];
         G2 g{};
+        g.x3 = c->x3;
         g.M = (int)Mpad; g.N = l.out_pad; g.K = l.in_pad; g.kchunk = g.K;
         g.A = c->act[i]; g.lda = l.in_pad; g.B = l.w32; g.ldb = l.in_pad;
         g.C = c->act[i + 1]; g.c_rs = l.out_pad; g.c_cs = 1; g.bias = l.b32;
@@ -2257,6 +2337,7 @@ extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x
     for (int i = c->n_lin - 1; i >= 0; --i) {
         MlpLayer& l = c->lin[i];
         G2 d{};
+        d.x3 = c->x3;
         d.M = (int)Mpad; d.N = l.in_pad; d.K = l.out_pad; d.kchunk = d.K;
         d.A = c->d[cur]; d.lda = l.out_pad; d.B = l.w32; d.ldb = l.in_pad;
         d.C = c->d[cur ^ 1]; d.c_rs = l.in_pad; d.c_cs = 1;
@@ -2266,6 +2347,7 @@ extern "C" int mtk_clf_guidance(mtk_clf* c, int64_t B, const float* x, int64_t x
     }
     {   // d x = d h0 . W_proj
         G2 d{};
+        d.x3 = c->x3;
         d.M = (int)Mpad; d.N = c->proj.in_pad; d.K = c->proj.out_pad; d.kchunk = d.K;
         d.A = c->d[cur]; d.lda = c->proj.out_pad; d.B = c->proj.w32; d.ldb = c->proj.in_pad;
         d.C = c->d[cur ^ 1]; d.c_rs = c->proj.in_pad; d.c_cs = 1;

@@ -1819,6 +1819,52 @@ def test_classifier_guidance_on_hip():
     assert torch.equal(one_stream, got)
 
 
+def test_classifier_guidance_split_bf16_mode():
+    """Classifier.precision = "bf16x3" (mtk_clf_set_precision; not in the reference): every GEMM of the guidance as a split-bf16
+    product of its fp32 operands (hi + lo bf16 numbers, three bf16 MFMAs per product, fp32 accumulation and storage: k_gemm2x).
+    Bar against the reference's own logits and input gradients: 1e-3 of their scale (measured ~1e-5; the margin is for a LeakyReLU
+    whose pre-activation sits at zero and flips).  Switching back restores the fp32 bits; out-of-range timesteps still poison their
+    rows; plain bf16 operands are refused (they do not carry the input gradient: DESIGN section 5)."""
+    import midst_toolkit_amd as mtk
+    from tests.helpers import load_classifier
+
+    c = load_classifier()
+    clf = mtk.Classifier(c["Nn"], c["n_classes"], 128, c["hidden"], dropout_prob=0.1).to(dev())
+    clf.load_state_dict(c["state"], strict=True)
+    clf.eval()
+    x, t, y = tt(c["x"]).to(dev()), tt(c["t"]).to(dev()), tt(c["y"]).to(dev())
+    cond = mtk.get_conditioning_function(clf, c["scale"])
+    with torch.no_grad():
+        exact_logits, exact_grad = clf(x, t), cond(x.double(), t, y=y)
+        clf.precision = "bf16x3"
+        logits, grad = clf(x, t), cond(x.double(), t, y=y)
+    want_l, want_g = tt(c["logits"]), tt(c["grad"])
+    assert not torch.equal(logits, exact_logits)  # the mode did switch
+    assert float((logits.cpu() - want_l).abs().max()) <= 1e-3 * float(want_l.abs().max())
+    assert float((grad.cpu() - want_g).abs().max()) <= 1e-3 * float(want_g.abs().max()), float((grad.cpu() - want_g).abs().max()) / float(want_g.abs().max())
+    # a larger, ragged batch: the typical row is at the fp32 path's own level
+    g = torch.Generator().manual_seed(3)
+    xb = torch.randn((3001, c["Nn"]), generator=g).to(dev())
+    tb = torch.randint(0, c["T"], (3001,), generator=g).to(dev())
+    yb = torch.randint(0, c["n_classes"], (3001,), generator=g).to(dev())
+    with torch.no_grad():
+        gs = cond(xb, tb, y=yb)
+        clf.precision = "fp32"
+        gf = cond(xb, tb, y=yb)
+    rel = ((gs - gf).norm(dim=1) / gf.norm(dim=1).clamp_min(1e-30)).cpu()
+    assert float(rel.median()) <= 1e-4 and float(rel.quantile(0.99)) <= 1e-3, (float(rel.median()), float(rel.quantile(0.99)))
+    clf.precision = "bf16x3"
+    tb2 = t.clone()
+    tb2[3] = -1
+    assert bool(cond(x, tb2, y=y)[3].isnan().all())
+    clf.precision = "fp32"
+    with torch.no_grad():
+        assert torch.equal(clf(x, t), exact_logits) and torch.equal(cond(x.double(), t, y=y), exact_grad)
+    clf.precision = "bf16"
+    with pytest.raises(ValueError):
+        clf(x, t)
+
+
 @pytest.mark.parametrize("tag,precision", [("M_mixed", "bf16"), ("B_ragged", "bf16x3"), ("B_ragged", "fp32")])
 def test_weight_update_with_unchanged_shapes_allocates_nothing(tag, precision):
     """mtk_mlp_set_weights: a second call with the same layer shapes takes every block of the old images back
