@@ -178,9 +178,10 @@ class Classifier(nn.Module):
                                       "Dropout), which is how the synthesizer calls it (TRAIN:447): call classifier.eval() first")
         dev = x.device
         h = self._engine(dev)
-        if self.precision not in ("fp32", "bf16x3"):
-            raise ValueError(f"Classifier.precision: {self.precision!r} (fp32 or bf16x3)")
-        check(_lib.lib().mtk_clf_set_precision(h, _lib.PREC_BF16X3 if self.precision == "bf16x3" else _lib.PREC_FP32))
+        precision = getattr(self, "precision", "fp32")  # objects pickled before the attribute existed
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"Classifier.precision: {precision!r} (fp32 or bf16x3)")
+        check(_lib.lib().mtk_clf_set_precision(h, _lib.PREC_BF16X3 if precision == "bf16x3" else _lib.PREC_FP32))
         xd = x.detach()
         if xd.dtype == torch.float32 and xd.is_contiguous():
             xf = xd
